@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the REFERENCE from /root/reference (build container only).
+
+The reference never travels to the GPU box; only the fixtures written here (inputs are NOT stored
+-- they are regenerated from the portable splitmix64 fill, oracle/fill.py -- plus expected outputs)
+are committed.  Re-run:  python tools/gen_golden.py     (needs /root/reference, CPU only)
+
+Fixture contents are data (numbers), never reference source text.
+"""
+import os, sys, json
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("SEG_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+
+from oracle.fill import fill, labels, fill_module          # noqa: E402
+from unet.unet import unet as RefUnet, DoubleConvReLU as RefDC, Down as RefDown, Up as RefUp  # noqa: E402
+from clip.clipunet import DecoderBlock as RefBlock, UNetDecoder as RefDecoder               # noqa: E402
+from utils.weighted_loss import WeightedDiceCELoss as RefDiceCE, \
+    WeightedMemoryEfficientDiceLoss as RefDice                                               # noqa: E402
+from utils.MetricsHistory import MetricsHistory as RefMetrics                                # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+META = {"torch": torch.__version__, "threads": torch.get_num_threads(), "dtype": "float32"}
+CW3 = [0.2046795970925636, 1.0271954434416883, 1.2293222812780409]
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def grad_summary(model):
+    """per-parameter grad L2 norm + first 8 values (full grads would be >100 MB for the U-Net)."""
+    names, norms, heads = [], [], []
+    for n, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        names.append(n)
+        norms.append(g.double().norm().item())
+        h = g.flatten()[:8]
+        heads.append(np.pad(npy(h), (0, 8 - h.numel())))
+    return np.array(names), np.array(norms), np.stack(heads)
+
+
+def save(name, **kw):
+    kw["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **kw)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in kw.items() if k != "meta"})
+
+
+def full_grads(model):
+    return {"grad." + n: npy(p.grad) for n, p in model.named_parameters()}
+
+
+def buffers(model):
+    return {"buf." + n: npy(b) for n, b in model.named_buffers()}
+
+
+# ---- A: DoubleConvReLU(3,8) (SURVEY 8c answer A) and a kernel-friendly (32,64) case ------------
+def gen_doubleconv(tag, din, dout, shape, base=1000):
+    m = RefDC(din, dout); fill_module(m, base); m.train()
+    x = fill(shape, 1, -1, 1).requires_grad_(True)
+    y = m(x)
+    gy = fill(tuple(y.shape), 5, -1, 1)
+    (y * gy).sum().backward()
+    save(tag, din=din, dout=dout, shape=np.array(shape), y=npy(y), dx=npy(x.grad),
+         **full_grads(m), **buffers(m))
+    m.eval()
+    with torch.no_grad():
+        save(tag + "_eval", y=npy(m(fill(shape, 1, -1, 1))))
+
+
+gen_doubleconv("doubleconv_3_8", 3, 8, (2, 3, 16, 16))
+gen_doubleconv("doubleconv_32_64", 32, 64, (2, 32, 24, 40))
+
+
+# ---- Down / Up blocks ---------------------------------------------------------------------------
+def gen_down():
+    m = RefDown(32, 64); fill_module(m, 2000); m.train()
+    x = fill((2, 32, 32, 32), 1, -1, 1).requires_grad_(True)
+    y = m(x); gy = fill(tuple(y.shape), 5, -1, 1); (y * gy).sum().backward()
+    save("down_32_64", y=npy(y), dx=npy(x.grad), **full_grads(m), **buffers(m))
+
+
+def gen_up():
+    m = RefUp(64, 32); fill_module(m, 3000); m.train()
+    x1 = fill((2, 32, 32, 32), 1, -1, 1).requires_grad_(True)
+    x2 = fill((2, 64, 16, 16), 2, -1, 1).requires_grad_(True)
+    y = m(x1, x2); gy = fill(tuple(y.shape), 5, -1, 1); (y * gy).sum().backward()
+    save("up_64_32", y=npy(y), dx1=npy(x1.grad), dx2=npy(x2.grad), **full_grads(m), **buffers(m))
+
+
+gen_down(); gen_up()
+
+
+# ---- B: unet(3,3) on 4x3x128x128 (BASELINE config 1; SURVEY 8c answer B) ------------------------
+def gen_unet():
+    m = RefUnet(3, 3); fill_module(m, 1000); m.train()
+    X = fill((4, 3, 128, 128), 1, 0, 1)
+    Y = labels((4, 1, 128, 128), 2, 3)
+    logits = m(X)
+    ce = torch.nn.CrossEntropyLoss()(logits, Y.squeeze(1))
+    w = torch.tensor(CW3)
+    wce = torch.nn.CrossEntropyLoss(weight=w)(logits, Y.squeeze(1))
+    dice = RefDice(smooth=1.0, class_weights=w)(logits, Y)
+    dicece = RefDiceCE(smooth_dice=1.0, class_weights=w)(logits, Y)
+    ce.backward()
+    names, norms, heads = grad_summary(m)
+    agg = RefMetrics(3)
+    for i in range(4):
+        agg.accumulate(logits[i].detach(), Y[i, 0])
+    mdice, miou, macc = agg.compute_epoch_metrics()
+    counts = np.stack([npy(agg.total_tp), npy(agg.total_fp), npy(agg.total_fn), npy(agg.total_tn)])
+    bufs = {"buf." + n: npy(b) for n, b in m.named_buffers() if b.numel() <= 64 or "down1" in n}
+    m.eval()
+    with torch.no_grad():
+        ev = m(X)
+    save("unet_3_3_b4_128", logits=npy(logits), ce=ce.item(), wce=wce.item(), dice=dice.item(),
+         dicece=dicece.item(), grad_names=names, grad_norms=norms, grad_heads=heads,
+         argmax=npy(logits.argmax(1)).astype(np.uint8), counts=counts,
+         metrics=np.array([mdice, miou, macc]), per_class_iou=npy(agg.get_last_per_class_iou()),
+         eval_logits_sum=ev.double().sum().item(), eval_logits_sample=npy(ev[:, :, ::16, ::16]), **bufs)
+
+    # a second, smaller full-model case whose dice+CE gradient is taken (config-5 style loss)
+    m2 = RefUnet(3, 3); fill_module(m2, 1000); m2.train()
+    X2 = fill((2, 3, 32, 48), 3, 0, 1); Y2 = labels((2, 1, 32, 48), 4, 3)
+    lg = m2(X2)
+    loss = RefDiceCE(smooth_dice=1.0, class_weights=w)(lg, Y2)
+    loss.backward()
+    n2, no2, h2 = grad_summary(m2)
+    save("unet_3_3_b2_32x48_dicece", logits=npy(lg), loss=loss.item(), grad_names=n2, grad_norms=no2,
+         grad_heads=h2)
+
+
+gen_unet()
+
+
+# ---- C/D: CLIP decoder (SURVEY 8c answers C, D) -------------------------------------------------
+def gen_clip():
+    blk = RefBlock(16, 12, 8); fill_module(blk, 7000); blk.train()
+    x = fill((1, 16, 3, 3), 31, -1, 1).requires_grad_(True)
+    sk = fill((1, 12, 3, 3), 32, -1, 1).requires_grad_(True)
+    y = blk(x, sk); gy = fill(tuple(y.shape), 5, -1, 1); (y * gy).sum().backward()
+    save("decoderblock_16_12_8", y=npy(y), dx=npy(x.grad), dskip=npy(sk.grad), **full_grads(blk),
+         **buffers(blk))
+
+    blk = RefBlock(64, 96, 32); fill_module(blk, 7100); blk.train()
+    x = fill((2, 64, 7, 7), 31, -1, 1).requires_grad_(True)
+    sk = fill((2, 96, 7, 7), 32, -1, 1).requires_grad_(True)
+    y = blk(x, sk); gy = fill(tuple(y.shape), 5, -1, 1); (y * gy).sum().backward()
+    save("decoderblock_64_96_32", y=npy(y), dx=npy(x.grad), dskip=npy(sk.grad), **full_grads(blk),
+         **buffers(blk))
+
+    dec = RefDecoder(768, [1024, 512, 256, 128, 64]); head = torch.nn.Conv2d(64, 4, 1)
+    both = torch.nn.ModuleDict({"decoder": dec, "output_layer": head})
+    fill_module(both, 5000); both.train()
+    x = fill((2, 768, 14, 14), 11, -1, 1)
+    skips = [fill((2, 768, 14, 14), 20 + i, -1, 1) for i in range(4)]
+    d = dec(x, skips); lg = head(d)
+    Y = labels((2, 224, 224), 3, 4)
+    ce = torch.nn.CrossEntropyLoss()(lg, Y); ce.backward()
+    names, norms, heads = grad_summary(both)
+    save("clip_decoder_b2", dec_sum=d.double().sum().item(), dec_max=d.max().item(),
+         logits_sum=lg.double().sum().item(), logits_sample=npy(lg[:, :, ::8, ::8]),
+         dec_sample=npy(d[:, :, ::16, ::16]), ce=ce.item(), grad_names=names, grad_norms=norms,
+         grad_heads=heads, argmax_sample=npy(lg.argmax(1)[:, ::4, ::4]).astype(np.uint8))
+
+
+gen_clip()
+
+
+# ---- losses on small logits with ignore_index, incl. gradient wrt logits ------------------------
+def gen_losses():
+    out = {}
+    lg0 = fill((2, 4, 12, 20), 41, -3, 3)
+    Y = labels((2, 12, 20), 42, 4)
+    w4 = torch.tensor([0.3, 1.1, 0.9, 1.7])
+    cases = {
+        "ce": lambda l: torch.nn.CrossEntropyLoss()(l, Y),
+        "ce_w": lambda l: torch.nn.CrossEntropyLoss(weight=w4)(l, Y),
+        "ce_w_ign3": lambda l: torch.nn.CrossEntropyLoss(weight=w4, ignore_index=3)(l, Y),
+        "dice": lambda l: RefDice(smooth=1e-5)(l, Y.unsqueeze(1)),
+        "dice_w_ign3": lambda l: RefDice(smooth=1.0, class_weights=w4, ignore_index=3)(l, Y.unsqueeze(1)),
+        "dicece": lambda l: RefDiceCE()(l, Y),
+        "dicece_w_ign3": lambda l: RefDiceCE(dice_weight=0.7, ce_weight=1.3, ignore_index=3,
+                                             class_weights=w4, smooth_dice=1.0)(l, Y.unsqueeze(1)),
+    }
+    for k, fn in cases.items():
+        l = lg0.clone().requires_grad_(True)
+        v = fn(l); v.backward()
+        out[k] = v.item(); out[k + "_grad"] = npy(l.grad)
+    save("losses_small", **out)
+
+
+gen_losses()
+
+
+# ---- train_loop protocol (training.py:18-64 driven by hand: torchvision/tqdm.notebook absent) ---
+def gen_trainloop():
+    res = {}
+    for acc in (1, 2):
+        m = RefUnet(3, 3); fill_module(m, 1000)
+        opt = torch.optim.AdamW(m.parameters(), weight_decay=0.01)
+        data = [(fill((2, 3, 32, 32), 10 + i, 0, 1), labels((2, 1, 32, 32), 20 + i, 3)) for i in range(3)]
+        loss_fn = torch.nn.CrossEntropyLoss()
+        m.train(); total, nproc, per = 0.0, 0, []
+        opt.zero_grad()
+        for bi, (X, y) in enumerate(data):                       # training.py:38-60
+            y = y.long()
+            pred = m(X)
+            loss = loss_fn(pred, y.squeeze(1))
+            (loss / acc).backward()
+            if (bi + 1) % acc == 0 or (bi + 1) == len(data):
+                opt.step(); opt.zero_grad()
+                total += loss.item(); nproc += 1; per.append(loss.item())
+        res[f"acc{acc}_avg"] = total / nproc
+        res[f"acc{acc}_losses"] = np.array(per)
+        # conv biases ahead of BN have zero true gradient (fp noise only): checksum the rest
+        res[f"acc{acc}_w0"] = npy(m.down1.doubleConvReLU[0].weight).copy()
+        res[f"acc{acc}_out_w"] = npy(m.output.weight).copy()
+        res[f"acc{acc}_rm"] = npy(m.down1.doubleConvReLU[1].running_mean).copy()
+    save("trainloop_unet_32", **res)
+
+
+gen_trainloop()
+print("done")
