@@ -1,0 +1,81 @@
+"""ctypes binding of libsegk.so (the C ABI declared in include/segk.h).
+
+The product path has NO CPU or eager-PyTorch fallback: if the HIP library is missing this module raises
+at first use, and every op raises RuntimeError(segk_last_error()) on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsegk.so")
+
+F32, BF16 = 0, 1
+MAX_CLASSES = 8
+
+_vp, _fp, _i, _l, _f, _d = C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+
+# name -> (restype, argtypes); mirrors include/segk.h one to one (checked by tests/test_abi.py)
+SIGNATURES = {
+    "segk_version": (_i, []),
+    "segk_last_error": (C.c_char_p, []),
+    "segk_nchw_to_nhwc": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_nhwc_to_nchw": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_pack_conv_weight": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_pack_convt_weight": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_conv_tiles": (_i, [_i, _i, _i]),
+    "segk_conv3x3": (_i, [_vp, _vp, _vp, _fp, _fp, _fp, _vp, _vp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_conv1x1": (_i, [_vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_convt2x2_fwd": (_i, [_vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_convt2x2_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_wgrad_tiles": (_i, [_i, _i, _i, _i, _i]),
+    "segk_wgrad": (_i, [_vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_wgrad_reduce": (_i, [_fp, _i, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_bn_finalize": (_i, [_fp, _i, _i, _i, _d, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _fp, _fp, _fp, _fp, _vp]),
+    "segk_bn_relu_apply": (_i, [_vp, _vp, _fp, _fp, _l, _i, _i, _vp]),
+    "segk_bn_bwd_blocks": (_i, [_l, _i, _i]),
+    "segk_bn_relu_bwd": (_i, [_vp, _vp, _vp, _fp, _fp, _fp, _fp, _l, _i, _i, _fp, _fp, _fp, _fp, _i, _vp]),
+    "segk_channel_sum": (_i, [_vp, _l, _i, _i, _fp, _fp, _i, _vp]),
+    "segk_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "segk_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_head_fwd": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_head_part_floats": (_i, [_l, _i]),
+    "segk_head_bwd": (_i, [_fp, _vp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_loss_part_floats": (_i, [_l]),
+    "segk_loss_state_floats": (_i, []),
+    "segk_loss_fwd": (_i, [_fp, _vp, _fp, _i, _i, _l, _i, _f, _f, _f, _fp, _fp, _vp]),
+    "segk_loss_bwd": (_i, [_fp, _vp, _fp, _fp, _fp, _i, _i, _l, _i, _f, _f, _fp, _vp]),
+    "segk_confusion": (_i, [_fp, _vp, _i, _i, _l, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsegk.so (building nothing: run `python -m image_segmentation_amd.build` or
+    __graft_entry__.build() first).  Raises if the library is absent -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU/eager fallback exists). "
+                "Build it with `python -m image_segmentation_amd.build`.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.segk_last_error().decode()}")
+
+
+def query(name, *args):
+    """Invoke a pure size/geometry query (returns its int result)."""
+    return getattr(load(), name)(*args)

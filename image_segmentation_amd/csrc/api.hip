@@ -1,0 +1,164 @@
+// extern "C" entry points declared in include/segk.h: argument validation + dispatch to the kernels.
+#include "common.hpp"
+#include "segk_internal.h"
+#include "../../include/segk.h"
+
+thread_local char g_segk_err[512] = "";
+
+// impl functions defined in the kernel translation units
+int segk_bn_finalize_impl(const float*, int, int, int, double, const float*, const float*, const float*, float*, float*,
+                          float, float, int, float*, float*, float*, float*, hipStream_t);
+int segk_bn_relu_apply_impl(const void*, void*, const float*, const float*, long, int, int, hipStream_t);
+int segk_bn_bwd_impl(const void*, const void*, void*, const float*, const float*, const float*, const float*, long, int,
+                     int, float*, float*, float*, float*, int, hipStream_t);
+int segk_channel_sum_impl(const void*, long, int, int, float*, float*, int, hipStream_t);
+int segk_maxpool_fwd_impl(const void*, void*, int, int, int, int, int, hipStream_t);
+int segk_maxpool_bwd_impl(const void*, const void*, void*, int, int, int, int, int, int, hipStream_t);
+int segk_nchw_to_nhwc_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
+int segk_nhwc_to_nchw_impl(const void*, float*, int, int, int, int, int, int, hipStream_t);
+int segk_pack_conv_weight_impl(const float*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int segk_pack_convt_weight_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
+int segk_wgrad_reduce_impl(const float*, int, float*, int, int, int, int, int, int, int, hipStream_t);
+int segk_head_fwd_impl(const void*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int segk_head_bwd_impl(const float*, const void*, const float*, void*, float*, float*, float*, int, int, int, int, int,
+                       int, int, hipStream_t);
+int segk_loss_fwd_impl(const float*, const long long*, const float*, int, int, long, int, float, float, float, float*,
+                       float*, hipStream_t);
+int segk_loss_bwd_impl(const float*, const long long*, const float*, const float*, const float*, int, int, long, int,
+                       float, float, float*, hipStream_t);
+int segk_confusion_impl(const float*, const long long*, int, int, long, unsigned long long*, hipStream_t);
+
+static inline int tile_twl(int W) { return W > 16 ? 5 : 4; }   // 8x32 tiles unless the image is <= 16 wide
+
+static void fill_tiles(ConvArgs& a) {
+  a.twl = tile_twl(a.W);
+  a.tiles_x = cdiv(a.W, 1 << a.twl);
+  a.tiles_y = cdiv(a.H, 256 >> a.twl);
+}
+
+extern "C" {
+
+int segk_version(void) { return 100; }
+const char* segk_last_error(void) { return g_segk_err; }
+
+int segk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cp, int dtype, segk_stream_t s) {
+  return segk_nchw_to_nhwc_impl(src, dst, B, C, H, W, Cp, dtype, (hipStream_t)s);
+}
+int segk_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cp, int dtype, segk_stream_t s) {
+  return segk_nhwc_to_nchw_impl(src, dst, B, C, H, W, Cp, dtype, (hipStream_t)s);
+}
+int segk_pack_conv_weight(const float* w, void* dst, int Cout, int CA, int CB, int Coutp, int CAp, int CBp, int taps,
+                          int mode, int dtype, segk_stream_t s) {
+  return segk_pack_conv_weight_impl(w, dst, Cout, CA, CB, Coutp, CAp, CBp, taps, mode, dtype, (hipStream_t)s);
+}
+int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cinp, int Coutp, int mode, int dtype,
+                           segk_stream_t s) {
+  return segk_pack_convt_weight_impl(w, dst, Cin, Cout, Cinp, Coutp, mode, dtype, (hipStream_t)s);
+}
+
+int segk_conv_tiles(int B, int H, int W) {
+  const int twl = tile_twl(W);
+  return B * cdiv(W, 1 << twl) * cdiv(H, 256 >> twl);
+}
+
+int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const float* bias, const float* scale,
+                 const float* shift, void* out, void* out2, float* stats, int B, int H, int W, int CA, int CB, int CO1,
+                 int CO2, int dtype, segk_stream_t s) {
+  ConvArgs a{};
+  a.srcA = srcA; a.srcB = srcB; a.w = wpacked; a.bias = bias; a.scale = scale; a.shift = shift;
+  a.out = out; a.out2 = out2; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.CA = CA; a.CB = CB; a.Ntot = CO1 + CO2; a.CO1 = CO1; a.CO2 = CO2;
+  fill_tiles(a);
+  return segk_conv_igemm_launch(a, 0, dtype, (hipStream_t)s);
+}
+
+int segk_conv1x1(const void* srcA, const void* wpacked, const float* bias, void* out, int B, int H, int W, int CA,
+                 int CO, int dtype, segk_stream_t s) {
+  ConvArgs a{};
+  a.srcA = srcA; a.w = wpacked; a.bias = bias; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.CA = CA; a.Ntot = CO; a.CO1 = CO;
+  fill_tiles(a);
+  return segk_conv_igemm_launch(a, 1, dtype, (hipStream_t)s);
+}
+
+int segk_convt2x2_fwd(const void* in, const void* wpacked, const float* bias4, void* out, int B, int H, int W, int Cin,
+                      int Cout, int dtype, segk_stream_t s) {
+  // bias4: per-N bias of length 4*Cout (the layer bias repeated for the four taps) or NULL
+  ConvArgs a{};
+  a.srcA = in; a.w = wpacked; a.bias = bias4; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.CA = Cin; a.Ntot = 4 * Cout; a.CO1 = Cout; a.shuffle = 1;
+  fill_tiles(a);
+  return segk_conv_igemm_launch(a, 1, dtype, (hipStream_t)s);
+}
+
+int segk_convt2x2_dgrad(const void* dout, const void* wpacked, void* din, int B, int H, int W, int Cin, int Cout,
+                        int dtype, segk_stream_t s) {
+  ConvArgs a{};
+  a.srcA = dout; a.w = wpacked; a.out = din;
+  a.B = B; a.H = H; a.W = W; a.CA = Cout; a.Ntot = Cin; a.CO1 = Cin; a.unshuf = 1;
+  fill_tiles(a);
+  return segk_conv_igemm_launch(a, 1, dtype, (hipStream_t)s);
+}
+
+int segk_wgrad(const void* dz, const void* srcA, const void* srcB, const float* scale, const float* shift, float* slabs,
+               int S, int B, int H, int W, int CD, int CA, int CB, int geo, int dtype, segk_stream_t s) {
+  WgradArgs a{};
+  a.dz = dz; a.srcA = srcA; a.srcB = srcB; a.scale = scale; a.shift = shift; a.slabs = slabs;
+  a.B = B; a.H = H; a.W = W; a.CD = CD; a.CA = CA; a.CB = CB; a.S = S;
+  return segk_wgrad_launch(a, geo, dtype, (hipStream_t)s);
+}
+int segk_wgrad_reduce(const float* slabs, int S, float* grad, int N, int CA, int CB, int Np, int CAp, int CBp, int taps,
+                      segk_stream_t s) {
+  return segk_wgrad_reduce_impl(slabs, S, grad, N, CA, CB, Np, CAp, CBp, taps, (hipStream_t)s);
+}
+
+int segk_bn_finalize(const float* stats, int tiles, int Cp, int C, double count, const float* conv_bias,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, int training, float* scale, float* shift, float* mean, float* rstd, segk_stream_t s) {
+  return segk_bn_finalize_impl(stats, tiles, Cp, C, count, conv_bias, gamma, beta, running_mean, running_var, momentum,
+                               eps, training, scale, shift, mean, rstd, (hipStream_t)s);
+}
+int segk_bn_relu_apply(const void* z, void* y, const float* scale, const float* shift, long P, int Cp, int dtype,
+                       segk_stream_t s) {
+  return segk_bn_relu_apply_impl(z, y, scale, shift, P, Cp, dtype, (hipStream_t)s);
+}
+int segk_bn_relu_bwd(const void* dy, const void* z, void* dz, const float* scale, const float* shift, const float* mean,
+                     const float* rstd, long P, int Cp, int C, float* part, float* dgamma, float* dbeta, float* coef,
+                     int dtype, segk_stream_t s) {
+  return segk_bn_bwd_impl(dy, z, dz, scale, shift, mean, rstd, P, Cp, C, part, dgamma, dbeta, coef, dtype,
+                          (hipStream_t)s);
+}
+int segk_channel_sum(const void* x, long P, int Cp, int C, float* part, float* out, int dtype, segk_stream_t s) {
+  return segk_channel_sum_impl(x, P, Cp, C, part, out, dtype, (hipStream_t)s);
+}
+int segk_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int Cp, int dtype, segk_stream_t s) {
+  return segk_maxpool_fwd_impl(x, y, B, H, W, Cp, dtype, (hipStream_t)s);
+}
+int segk_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate, int dtype,
+                        segk_stream_t s) {
+  return segk_maxpool_bwd_impl(x, dy, dx, B, H, W, Cp, accumulate, dtype, (hipStream_t)s);
+}
+int segk_head_fwd(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp, int C,
+                  int ncls, int dtype, segk_stream_t s) {
+  return segk_head_fwd_impl(y, w, bias, logits, B, H, W, Cp, C, ncls, dtype, (hipStream_t)s);
+}
+int segk_head_bwd(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
+                  int B, int H, int W, int Cp, int C, int ncls, int dtype, segk_stream_t s) {
+  return segk_head_bwd_impl(dlogits, y, w, dy, part, dw, db, B, H, W, Cp, C, ncls, dtype, (hipStream_t)s);
+}
+int segk_loss_fwd(const float* logits, const int64_t* labels, const float* cw, int N, int C, long HW, int ignore_index,
+                  float smooth, float dice_weight, float ce_weight, float* part, float* state, segk_stream_t s) {
+  return segk_loss_fwd_impl(logits, (const long long*)labels, cw, N, C, HW, ignore_index, smooth, dice_weight, ce_weight,
+                            part, state, (hipStream_t)s);
+}
+int segk_loss_bwd(const float* logits, const int64_t* labels, const float* cw, const float* state, const float* gout,
+                  int N, int C, long HW, int ignore_index, float dice_weight, float ce_weight, float* dlogits,
+                  segk_stream_t s) {
+  return segk_loss_bwd_impl(logits, (const long long*)labels, cw, state, gout, N, C, HW, ignore_index, dice_weight,
+                            ce_weight, dlogits, (hipStream_t)s);
+}
+int segk_confusion(const float* logits, const int64_t* labels, int N, int C, long HW, uint64_t* M, segk_stream_t s) {
+  return segk_confusion_impl(logits, (const long long*)labels, N, C, HW, (unsigned long long*)M, (hipStream_t)s);
+}
+
+}  // extern "C"

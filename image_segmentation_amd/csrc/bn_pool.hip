@@ -1,0 +1,464 @@
+// BatchNorm2d (train/eval) finalisation, BN+ReLU apply, BN backward reductions, MaxPool2d(2,2)
+// forward/backward on NHWC tensors.  HBM-bound streaming kernels: every thread owns one 16-byte
+// channel vector (fixed channels -> per-channel constants live in registers) and walks pixels, so a
+// row of threads reads/writes whole contiguous pixel rows (coalesced 16 B per lane).
+//
+// Reference semantics: torch.nn.BatchNorm2d as instantiated at unet/unet.py:17,20 and
+// clip/clipunet.py:88,91 (eps 1e-5, momentum 0.1, biased variance to normalise, unbiased variance into
+// running_var), nn.ReLU, nn.MaxPool2d(2,2) at unet.py:40 (backward routes to the first maximum in
+// row-major window order).
+#include "common.hpp"
+#include "segk_internal.h"
+#include "../../include/segk.h"
+
+namespace {
+
+// block = CVB channel-vectors x ROWS pixel lanes (CVB*ROWS <= 256); grid.y covers channel blocks.
+struct Lanes {
+  int cx, ry, cv;
+  bool active;
+};
+__device__ __forceinline__ Lanes lanes(int cvb, int cvec) {
+  Lanes l;
+  l.cx = threadIdx.x % cvb;
+  l.ry = threadIdx.x / cvb;
+  l.cv = blockIdx.y * cvb + l.cx;
+  l.active = l.cv < cvec;
+  return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stats partials [MT][C][2] (sum, sumsq of the bias-free conv output) -> scale/shift (+ running stats)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int MT, int C, int C_real,
+                                                          double count, const float* conv_bias,
+                                                          const float* gamma, const float* beta, float* rmean,
+                                                          float* rvar, float momentum, float eps, int training,
+                                                          float* scale, float* shift, float* mean_out,
+                                                          float* rstd_out) {
+  __shared__ double sh[8][32][2];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double s1 = 0.0, s2 = 0.0;
+  if (training && c < C)
+    for (int m = ry; m < MT; m += 8) {
+      const float2 v = ((const float2*)part)[(size_t)m * C + c];
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  sh[ry][cx][0] = s1;
+  sh[ry][cx][1] = s2;
+  __syncthreads();
+  if (ry != 0 || c >= C) return;
+  if (c >= C_real) {  // padded channel: stays identically zero
+    scale[c] = 0.f; shift[c] = 0.f;
+    if (mean_out) { mean_out[c] = 0.f; rstd_out[c] = 0.f; }
+    return;
+  }
+  const float g = gamma[c], be = beta[c];
+  const float cb = conv_bias ? conv_bias[c] : 0.f;
+  if (training) {
+    s1 = 0.0; s2 = 0.0;
+    for (int r = 0; r < 8; ++r) { s1 += sh[r][cx][0]; s2 += sh[r][cx][1]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = g * rstd;
+    scale[c] = sc;
+    shift[c] = be - (float)mean * sc;      // applied to the bias-free conv output: the bias cancels
+    mean_out[c] = (float)mean;
+    rstd_out[c] = rstd;
+    if (rmean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * ((float)mean + cb);
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+  } else {
+    const float rstd = 1.f / sqrtf(rvar[c] + eps);
+    const float sc = g * rstd;
+    scale[c] = sc;
+    shift[c] = be + (cb - rmean[c]) * sc;
+    if (mean_out) { mean_out[c] = rmean[c] - cb; rstd_out[c] = rstd; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = relu(z*scale + shift)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ z, T* __restrict__ y,
+                                                            const float* scale, const float* shift, long P, int C,
+                                                            int cvb, int rows) {
+  using E = ET<T>;
+  const Lanes l = lanes(cvb, C / E::VEC);
+  if (!l.active || l.ry >= rows) return;
+  float sc[E::VEC], sh[E::VEC];
+#pragma unroll
+  for (int j = 0; j < E::VEC; ++j) { sc[j] = scale[l.cv * E::VEC + j]; sh[j] = shift[l.cv * E::VEC + j]; }
+  for (long p = (long)blockIdx.x * rows + l.ry; p < P; p += (long)gridDim.x * rows) {
+    const size_t off = (size_t)p * C + l.cv * E::VEC;
+    float f[E::VEC];
+    unpack16<T>(*(const uint4*)(z + off), f);
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
+    *(uint4*)(y + off) = pack16<T>(f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN backward pass 1: g = dy * [z*scale+shift > 0];  partial sums of g and g*xhat per channel.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                            const float* scale, const float* shift,
+                                                            const float* mean, const float* rstd, long P, int C,
+                                                            int cvb, int rows, float* part) {
+  using E = ET<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [rows][cvb][2*VEC]
+  const Lanes l = lanes(cvb, C / E::VEC);
+  float sg[E::VEC], sgx[E::VEC];
+#pragma unroll
+  for (int j = 0; j < E::VEC; ++j) { sg[j] = 0.f; sgx[j] = 0.f; }
+  if (l.active && l.ry < rows) {
+    float sc[E::VEC], sh[E::VEC], mu[E::VEC], rs[E::VEC];
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) {
+      const int c = l.cv * E::VEC + j;
+      sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
+    }
+    for (long p = (long)blockIdx.x * rows + l.ry; p < P; p += (long)gridDim.x * rows) {
+      const size_t off = (size_t)p * C + l.cv * E::VEC;
+      float fz[E::VEC], fd[E::VEC];
+      unpack16<T>(*(const uint4*)(z + off), fz);
+      unpack16<T>(*(const uint4*)(dy + off), fd);
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) {
+        const float g = (fmaf(fz[j], sc[j], sh[j]) > 0.f) ? fd[j] : 0.f;
+        sg[j] += g;
+        sgx[j] = fmaf(g, (fz[j] - mu[j]) * rs[j], sgx[j]);
+      }
+    }
+  }
+  if (l.ry < rows) {
+    float* r = red + ((size_t)l.ry * cvb + l.cx) * (2 * E::VEC);
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) { r[j] = sg[j]; r[E::VEC + j] = sgx[j]; }
+  }
+  __syncthreads();
+  if (l.ry == 0 && l.active) {
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < rows; ++r) {  // fixed order
+        const float* q = red + ((size_t)r * cvb + l.cx) * (2 * E::VEC);
+        a += q[j];
+        b += q[E::VEC + j];
+      }
+      float2* dst = (float2*)part + (size_t)blockIdx.x * C + l.cv * E::VEC + j;
+      *dst = make_float2(a, b);
+    }
+  }
+}
+
+// partials [NB][C][2] -> dgamma, dbeta, coef = (sum_g/N, sum_gx/N)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int NB, int C,
+                                                              int C_real, double count, float* dgamma, float* dbeta,
+                                                              float* coef) {
+  __shared__ double sh[8][32][2];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int m = ry; m < NB; m += 8) {
+      const float2 v = ((const float2*)part)[(size_t)m * C + c];
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  sh[ry][cx][0] = s1;
+  sh[ry][cx][1] = s2;
+  __syncthreads();
+  if (ry != 0 || c >= C) return;
+  s1 = 0.0; s2 = 0.0;
+  for (int r = 0; r < 8; ++r) { s1 += sh[r][cx][0]; s2 += sh[r][cx][1]; }
+  if (c < C_real) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+  coef[2 * c] = (float)(s1 / count);
+  coef[2 * c + 1] = (float)(s2 / count);
+}
+
+// BN backward pass 2 (in place allowed): dz = scale * (g - c1 - xhat*c2)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                           T* __restrict__ dz, const float* scale,
+                                                           const float* shift, const float* mean, const float* rstd,
+                                                           const float* coef, long P, int C, int cvb, int rows) {
+  using E = ET<T>;
+  const Lanes l = lanes(cvb, C / E::VEC);
+  if (!l.active || l.ry >= rows) return;
+  float sc[E::VEC], sh[E::VEC], mu[E::VEC], rs[E::VEC], c1[E::VEC], c2[E::VEC];
+#pragma unroll
+  for (int j = 0; j < E::VEC; ++j) {
+    const int c = l.cv * E::VEC + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
+    c1[j] = coef[2 * c]; c2[j] = coef[2 * c + 1];
+  }
+  for (long p = (long)blockIdx.x * rows + l.ry; p < P; p += (long)gridDim.x * rows) {
+    const size_t off = (size_t)p * C + l.cv * E::VEC;
+    float fz[E::VEC], fd[E::VEC];
+    unpack16<T>(*(const uint4*)(z + off), fz);
+    unpack16<T>(*(const uint4*)(dy + off), fd);
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) {
+      const float g = (fmaf(fz[j], sc[j], sh[j]) > 0.f) ? fd[j] : 0.f;
+      const float xh = (fz[j] - mu[j]) * rs[j];
+      fd[j] = sc[j] * (g - c1[j] - xh * c2[j]);
+    }
+    *(uint4*)(dz + off) = pack16<T>(fd);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
+                                                          int W, int C) {
+  using E = ET<T>;
+  const int Ho = H >> 1, Wo = W >> 1, CV = C / E::VEC;
+  const long total = (long)B * Ho * Wo * CV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int xo = (int)(p % Wo); p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const T* src = x + (((size_t)(b * H + 2 * yo)) * W + 2 * xo) * C + cv * E::VEC;
+    float f0[E::VEC], f1[E::VEC], f2[E::VEC], f3[E::VEC];
+    unpack16<T>(*(const uint4*)src, f0);
+    unpack16<T>(*(const uint4*)(src + C), f1);
+    unpack16<T>(*(const uint4*)(src + (size_t)W * C), f2);
+    unpack16<T>(*(const uint4*)(src + (size_t)W * C + C), f3);
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) f0[j] = fmaxf(fmaxf(f0[j], f1[j]), fmaxf(f2[j], f3[j]));
+    *(uint4*)(y + (((size_t)(b * Ho + yo)) * Wo + xo) * C + cv * E::VEC) = pack16<T>(f0);
+  }
+}
+
+// dx (+)= route(dy) ; one thread per 2x2 window x channel vector (windows tile the even part of the image)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          T* __restrict__ dx, int B, int H, int W, int C,
+                                                          int accumulate) {
+  using E = ET<T>;
+  const int Ho = H >> 1, Wo = W >> 1, CV = C / E::VEC;
+  const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;  // also visit the odd border (gradient zero there)
+  const long total = (long)B * Hc * Wc * CV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int xo = (int)(p % Wc); p /= Wc;
+    const int yo = (int)(p % Hc);
+    const int b = (int)(p / Hc);
+    const bool inwin = (yo < Ho) && (xo < Wo);
+    float g[E::VEC];
+    float v[4][E::VEC];
+    if (inwin) unpack16<T>(*(const uint4*)(dy + (((size_t)(b * Ho + yo)) * Wo + xo) * C + cv * E::VEC), g);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
+      if (inwin) unpack16<T>(*(const uint4*)(x + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC), v[k]);
+    }
+    int sel[E::VEC];
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) {
+      sel[j] = 0;
+      if (inwin) {
+        float m = v[0][j];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+          if (v[k][j] > m) { m = v[k][j]; sel[j] = k; }  // strict '>' keeps the FIRST maximum
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
+      if (yy >= H || xx >= W) continue;
+      T* dst = dx + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC;
+      float o[E::VEC];
+      if (accumulate) unpack16<T>(*(const uint4*)dst, o);
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) {
+        const float r = (inwin && sel[j] == k) ? g[j] : 0.f;
+        o[j] = accumulate ? o[j] + r : r;
+      }
+      *(uint4*)dst = pack16<T>(o);
+    }
+  }
+}
+
+// per-channel sum over pixels (bias gradient of ConvTranspose2d / 1x1 Conv2d): partials [gridDim.x][C]
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, long P, int C, int cvb, int rows,
+                                                          float* part) {
+  using E = ET<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [rows][cvb][VEC]
+  const Lanes l = lanes(cvb, C / E::VEC);
+  float s[E::VEC];
+#pragma unroll
+  for (int j = 0; j < E::VEC; ++j) s[j] = 0.f;
+  if (l.active && l.ry < rows)
+    for (long p = (long)blockIdx.x * rows + l.ry; p < P; p += (long)gridDim.x * rows) {
+      float f[E::VEC];
+      unpack16<T>(*(const uint4*)(x + (size_t)p * C + l.cv * E::VEC), f);
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) s[j] += f[j];
+    }
+  if (l.ry < rows) {
+    float* r = red + ((size_t)l.ry * cvb + l.cx) * E::VEC;
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) r[j] = s[j];
+  }
+  __syncthreads();
+  if (l.ry == 0 && l.active)
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) {
+      float a = 0.f;
+      for (int r = 0; r < rows; ++r) a += red[((size_t)r * cvb + l.cx) * E::VEC + j];
+      part[(size_t)blockIdx.x * C + l.cv * E::VEC + j] = a;
+    }
+}
+__global__ void channel_sum_finalize_kernel(const float* __restrict__ part, int NB, int C, int C_real, float* out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C_real) return;
+  double s = 0.0;
+  for (int b = 0; b < NB; ++b) s += (double)part[(size_t)b * C + c];
+  out[c] = (float)s;
+}
+
+static inline void lane_geometry(int C, int vec, int* cvb, int* rows, int* gy) {
+  const int cvec = C / vec;
+  *cvb = cvec < 128 ? cvec : 128;
+  *rows = 256 / *cvb;
+  *gy = cdiv(cvec, *cvb);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+int segk_bn_finalize_impl(const float* part, int MT, int C, int C_real, double count, const float* conv_bias,
+                          const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                          int training, float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
+  SEGK_REQUIRE(C > 0 && C % 32 == 0 && C_real > 0 && C_real <= C, "bn_finalize: bad channels C=%d real=%d", C, C_real);
+  SEGK_REQUIRE(gamma && beta && scale && shift, "bn_finalize: null pointer");
+  if (training) SEGK_REQUIRE(part && MT > 0 && count > 0 && mean && rstd, "bn_finalize: training needs partials");
+  else SEGK_REQUIRE(rmean && rvar, "bn_finalize: eval needs running statistics");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 32), dim3(256), 0, st, part, MT, C, C_real, count, conv_bias, gamma,
+                     beta, rmean, rvar, momentum, eps, training, scale, shift, mean, rstd);
+  SEGK_CHECK_LAUNCH("bn_finalize");
+  return 0;
+}
+
+template <typename T>
+static int bn_relu_apply_t(const void* z, void* y, const float* scale, const float* shift, long P, int C, hipStream_t st) {
+  int cvb, rows, gy;
+  lane_geometry(C, ET<T>::VEC, &cvb, &rows, &gy);
+  long gx = (P + rows - 1) / rows;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3((int)gx, gy), dim3(256), 0, st, (const T*)z, (T*)y, scale, shift, P,
+                     C, cvb, rows);
+  SEGK_CHECK_LAUNCH("bn_relu_apply");
+  return 0;
+}
+int segk_bn_relu_apply_impl(const void* z, void* y, const float* scale, const float* shift, long P, int C, int dtype,
+                            hipStream_t st) {
+  SEGK_REQUIRE(z && y && scale && shift && P > 0 && C > 0 && C % 32 == 0, "bn_relu_apply: bad arguments");
+  return dtype == SEGK_DT_BF16 ? bn_relu_apply_t<bf16_t>(z, y, scale, shift, P, C, st)
+                               : bn_relu_apply_t<float>(z, y, scale, shift, P, C, st);
+}
+
+int segk_bn_bwd_blocks(long P, int C, int dtype) {
+  const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
+  int cvb, rows, gy;
+  lane_geometry(C, vec, &cvb, &rows, &gy);
+  long gx = (P + rows - 1) / rows;
+  if (gx > 1024) gx = 1024;
+  return (int)gx;
+}
+
+template <typename T>
+static int bn_bwd_t(const void* dy, const void* z, void* dz, const float* scale, const float* shift, const float* mean,
+                    const float* rstd, long P, int C, int C_real, float* part, float* dgamma, float* dbeta,
+                    float* coef, hipStream_t st) {
+  using E = ET<T>;
+  int cvb, rows, gy;
+  lane_geometry(C, E::VEC, &cvb, &rows, &gy);
+  const int gx = segk_bn_bwd_blocks(P, C, sizeof(T) == 2 ? SEGK_DT_BF16 : SEGK_DT_F32);
+  const size_t lds = (size_t)rows * cvb * 2 * E::VEC * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gx, gy), dim3(256), lds, st, (const T*)dy, (const T*)z, scale, shift,
+                     mean, rstd, P, C, cvb, rows, part);
+  SEGK_CHECK_LAUNCH("bn_bwd_reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32), dim3(256), 0, st, part, gx, C, C_real, (double)P, dgamma,
+                     dbeta, coef);
+  SEGK_CHECK_LAUNCH("bn_bwd_finalize");
+  long ga = (P + rows - 1) / rows;
+  if (ga > 4096) ga = 4096;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((int)ga, gy), dim3(256), 0, st, (const T*)dy, (const T*)z, (T*)dz,
+                     scale, shift, mean, rstd, coef, P, C, cvb, rows);
+  SEGK_CHECK_LAUNCH("bn_bwd_apply");
+  return 0;
+}
+int segk_bn_bwd_impl(const void* dy, const void* z, void* dz, const float* scale, const float* shift, const float* mean,
+                     const float* rstd, long P, int C, int C_real, float* part, float* dgamma, float* dbeta, float* coef,
+                     int dtype, hipStream_t st) {
+  SEGK_REQUIRE(dy && z && dz && scale && shift && mean && rstd && part && dgamma && dbeta && coef,
+               "bn_bwd: null pointer");
+  SEGK_REQUIRE(P > 0 && C > 0 && C % 32 == 0 && C_real > 0 && C_real <= C, "bn_bwd: bad shape");
+  return dtype == SEGK_DT_BF16
+             ? bn_bwd_t<bf16_t>(dy, z, dz, scale, shift, mean, rstd, P, C, C_real, part, dgamma, dbeta, coef, st)
+             : bn_bwd_t<float>(dy, z, dz, scale, shift, mean, rstd, P, C, C_real, part, dgamma, dbeta, coef, st);
+}
+
+int segk_maxpool_fwd_impl(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(x && y && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 32 == 0, "maxpool_fwd: bad arguments");
+  const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
+  long total = (long)B * (H / 2) * (W / 2) * (C / vec);
+  long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (dtype == SEGK_DT_BF16)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3((int)g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3((int)g), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
+  SEGK_CHECK_LAUNCH("maxpool_fwd");
+  return 0;
+}
+
+int segk_maxpool_bwd_impl(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int accumulate, int dtype,
+                          hipStream_t st) {
+  SEGK_REQUIRE(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 32 == 0, "maxpool_bwd: bad arguments");
+  const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
+  long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec);
+  long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (dtype == SEGK_DT_BF16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3((int)g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       (bf16_t*)dx, B, H, W, C, accumulate);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((int)g), dim3(256), 0, st, (const float*)x, (const float*)dy,
+                       (float*)dx, B, H, W, C, accumulate);
+  SEGK_CHECK_LAUNCH("maxpool_bwd");
+  return 0;
+}
+
+int segk_channel_sum_impl(const void* x, long P, int C, int C_real, float* part, float* out, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(x && part && out && P > 0 && C > 0 && C % 32 == 0 && C_real > 0 && C_real <= C, "channel_sum: bad arguments");
+  const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
+  int cvb, rows, gy;
+  lane_geometry(C, vec, &cvb, &rows, &gy);
+  const int gx = segk_bn_bwd_blocks(P, C, dtype);
+  const size_t lds = (size_t)rows * cvb * vec * sizeof(float);
+  if (dtype == SEGK_DT_BF16)
+    hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(gx, gy), dim3(256), lds, st, (const bf16_t*)x, P, C, cvb, rows, part);
+  else
+    hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(gx, gy), dim3(256), lds, st, (const float*)x, P, C, cvb, rows, part);
+  SEGK_CHECK_LAUNCH("channel_sum");
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(cdiv(C_real, 256)), dim3(256), 0, st, part, gx, C, C_real, out);
+  SEGK_CHECK_LAUNCH("channel_sum_finalize");
+  return 0;
+}

@@ -1,0 +1,90 @@
+// Shared device/host helpers for the segk kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define SEGK_DT_F32 0
+#define SEGK_DT_BF16 1
+
+// ---- error plumbing (thread-local message, negative return codes; no exceptions cross the ABI)
+extern thread_local char g_segk_err[512];
+#define SEGK_FAIL(code, ...)                                   \
+  do {                                                         \
+    snprintf(g_segk_err, sizeof(g_segk_err), __VA_ARGS__);     \
+    return (code);                                             \
+  } while (0)
+#define SEGK_REQUIRE(cond, ...)                                \
+  do {                                                         \
+    if (!(cond)) SEGK_FAIL(-2, __VA_ARGS__);                   \
+  } while (0)
+#define SEGK_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess) SEGK_FAIL(-3, "%s: launch failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- element traits: one 16-byte LDS/global vector holds VEC elements
+template <typename T> struct ET;
+template <> struct ET<float> {
+  static constexpr int VEC = 4;     // elements per 16 B
+  static constexpr int ES = 4;      // element size
+  static constexpr int CH = 16;     // channels per 64-byte K-chunk
+};
+template <> struct ET<bf16_t> {
+  static constexpr int VEC = 8;
+  static constexpr int ES = 2;
+  static constexpr int CH = 32;
+};
+
+__device__ __forceinline__ float bf2f(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+
+// unpack a 16-byte vector of T into floats
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+  f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, float* f) {
+  f[0] = bf2f(v.x & 0xffffu); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = bf2f(v.y & 0xffffu); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = bf2f(v.z & 0xffffu); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = bf2f(v.w & 0xffffu); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
+  uint16_t ua = __builtin_bit_cast(uint16_t, a), ub = __builtin_bit_cast(uint16_t, b);
+  return (uint32_t)ua | ((uint32_t)ub << 16);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
+  return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                    pack_bf16x2(f[6], f[7]));
+}
+template <typename T> __device__ __forceinline__ T from_float(float f);
+template <> __device__ __forceinline__ float from_float<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t from_float<bf16_t>(float f) { return (bf16_t)f; }
+template <typename T> __device__ __forceinline__ float to_float(T v);
+template <> __device__ __forceinline__ float to_float<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_float<bf16_t>(bf16_t v) { return (float)v; }
+
+// XCD-aware block remap: blocks b and b+8 share an XCD (observed round-robin dispatch; speed only).
+// Gives each XCD a contiguous range of logical ids so neighbouring tiles share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

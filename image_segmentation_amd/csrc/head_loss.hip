@@ -1,0 +1,449 @@
+// Output head (1x1 Conv2d to a handful of classes), per-pixel CrossEntropy + soft-Dice loss, and the
+// argmax/confusion-count metric kernel.  All HBM-bound; logits are fp32 NCHW exactly like the reference
+// returns them (unet/unet.py:91,105; clip/clipunet.py:181,187).
+//
+// Loss semantics (one fused pass over logits + labels):
+//   CE   : nn.CrossEntropyLoss(mean, optional weight / ignore_index)  -- utils/training.py:47,
+//          utils/weighted_loss.py:132-138,163:  sum_p w[y_p] * nll_p / sum_p w[y_p] over non-ignored pixels
+//   Dice : utils/weighted_loss.py:31-98: p = softmax; per class I = sum p*onehot, Sp = sum p, Sg = sum onehot
+//          over N,H,W; dc = (2I+s)/clip(Sp+Sg+s, 1e-8); (weighted) mean over non-ignored classes; loss = -mean
+//   combined = dice_weight * dice + ce_weight * ce   (weighted_loss.py:165)
+// Metric: utils/MetricsHistory.py:65-75 (argmax -> first maximum, per-class TP/FP/FN/TN).
+#include "common.hpp"
+#include "segk_internal.h"
+#include "../../include/segk.h"
+
+namespace {
+constexpr int MAXC = 8;    // classes supported by the fused kernels
+constexpr int HT = 256;    // pixels per head tile (one per thread)
+constexpr int HCH = 64;    // channels staged per pass
+
+// ------------------------------------------------------------------------------------------------
+// logits[b][k][y][x] = bias[k] + sum_c y[p][c] * Wt[k][c]
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ logits,
+                                                       long P, long HW, int Cp, int C, int ncls) {
+  using E = ET<T>;
+  constexpr int PITCH = HCH * E::ES + 16;
+  extern __shared__ __attribute__((aligned(16))) char tile[];   // HT * PITCH bytes
+  __shared__ float ws[MAXC * HCH];
+  const int tid = threadIdx.x;
+  for (long p0 = (long)blockIdx.x * HT; p0 < P; p0 += (long)gridDim.x * HT) {
+    float acc[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) acc[k] = (k < ncls) ? bias[k] : 0.f;
+    for (int c0 = 0; c0 < Cp; c0 += HCH) {
+      __syncthreads();
+      constexpr int VPR = HCH / E::VEC;  // 16-byte vectors per pixel row of this pass
+      for (int q = tid; q < HT * VPR; q += 256) {
+        const int px = q / VPR, v = q - px * VPR;
+        uint4 d = make_uint4(0, 0, 0, 0);
+        if (p0 + px < P && c0 + v * E::VEC < Cp) d = *(const uint4*)(y + (size_t)(p0 + px) * Cp + c0 + v * E::VEC);
+        *(uint4*)(tile + px * PITCH + v * 16) = d;
+      }
+      for (int q = tid; q < MAXC * HCH; q += 256) {
+        const int k = q / HCH, c = c0 + (q - k * HCH);
+        ws[q] = (k < ncls && c < C) ? w[(size_t)k * C + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int v = 0; v < VPR; ++v) {
+        float f[E::VEC];
+        unpack16<T>(*(const uint4*)(tile + tid * PITCH + v * 16), f);
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j)
+#pragma unroll
+          for (int k = 0; k < MAXC; ++k) acc[k] = fmaf(f[j], ws[k * HCH + v * E::VEC + j], acc[k]);
+      }
+    }
+    const long p = p0 + tid;
+    if (p < P) {
+      const long b = p / HW, r = p - b * HW;
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k)
+        if (k < ncls) logits[(b * ncls + k) * HW + r] = acc[k];
+    }
+  }
+}
+
+// dy[p][c] = sum_k dl[p][k] * W[k][c];  partial dW[k][c] = sum_p dl[p][k]*y[p][c], db[k] = sum_p dl[p][k]
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlog, const T* __restrict__ y,
+                                                       const float* __restrict__ w, T* __restrict__ dy,
+                                                       float* __restrict__ part, long P, long HW, int Cp, int C,
+                                                       int ncls) {
+  using E = ET<T>;
+  constexpr int PITCH = HCH * E::ES + 16;
+  extern __shared__ __attribute__((aligned(16))) char tile[];   // HT * PITCH bytes
+  __shared__ float ws[MAXC * HCH];
+  __shared__ float dls[HT * MAXC];
+  __shared__ float red[4][MAXC][HCH];
+  const int tid = threadIdx.x;
+  const int cl = tid & (HCH - 1), pg = tid >> 6;  // channel lane / pixel group (4 groups of 64 pixels)
+  const int npass = (Cp + HCH - 1) / HCH;
+  // per-thread partial sums for (k, channel cl) of every pass live in LDS-free registers: one pass at a time
+  for (int pass = 0; pass < npass; ++pass) {
+    const int c0 = pass * HCH;
+    float aw[MAXC], ab[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
+    for (long p0 = (long)blockIdx.x * HT; p0 < P; p0 += (long)gridDim.x * HT) {
+      __syncthreads();
+      constexpr int VPR = HCH / E::VEC;
+      for (int q = tid; q < HT * VPR; q += 256) {
+        const int px = q / VPR, v = q - px * VPR;
+        uint4 d = make_uint4(0, 0, 0, 0);
+        if (p0 + px < P && c0 + v * E::VEC < Cp) d = *(const uint4*)(y + (size_t)(p0 + px) * Cp + c0 + v * E::VEC);
+        *(uint4*)(tile + px * PITCH + v * 16) = d;
+      }
+      for (int q = tid; q < MAXC * HCH; q += 256) {
+        const int k = q / HCH, c = c0 + (q - k * HCH);
+        ws[q] = (k < ncls && c < C) ? w[(size_t)k * C + c] : 0.f;
+      }
+      {
+        const long p = p0 + tid;
+        const long b = p / HW, r = p - b * HW;
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) dls[tid * MAXC + k] = (p < P && k < ncls) ? dlog[(b * ncls + k) * HW + r] : 0.f;
+      }
+      __syncthreads();
+      // weight-gradient partials: thread (cl, pg) walks the 64 pixels of its group down one channel column
+      for (int i = 0; i < 64; ++i) {
+        const int px = pg * 64 + i;
+        const float yv = to_float<T>(*(const T*)(tile + px * PITCH + cl * E::ES));
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+          const float d = dls[px * MAXC + k];
+          aw[k] = fmaf(d, yv, aw[k]);
+          if (pass == 0 && cl == 0) ab[k] += d;
+        }
+      }
+      __syncthreads();
+      // data gradient: thread per pixel, overwrite the tile in place, then coalesced store
+      {
+        float dl[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) dl[k] = dls[tid * MAXC + k];
+#pragma unroll 4
+        for (int v = 0; v < VPR; ++v) {
+          float f[E::VEC];
+#pragma unroll
+          for (int j = 0; j < E::VEC; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) s = fmaf(dl[k], ws[k * HCH + v * E::VEC + j], s);
+            f[j] = s;
+          }
+          *(uint4*)(tile + tid * PITCH + v * 16) = pack16<T>(f);
+        }
+      }
+      __syncthreads();
+      for (int q = tid; q < HT * VPR; q += 256) {
+        const int px = q / VPR, v = q - px * VPR;
+        if (p0 + px < P && c0 + v * E::VEC < Cp)
+          *(uint4*)(dy + (size_t)(p0 + px) * Cp + c0 + v * E::VEC) = *(const uint4*)(tile + px * PITCH + v * 16);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) red[pg][k][cl] = aw[k];
+    __syncthreads();
+    if (pg == 0) {
+      // part layout: [block][MAXC][Cp + 1]  (last column = bias gradient)
+      float* dst = part + (size_t)blockIdx.x * MAXC * (Cp + 1);
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k)
+        if (c0 + cl < Cp) dst[k * (Cp + 1) + c0 + cl] = red[0][k][cl] + red[1][k][cl] + red[2][k][cl] + red[3][k][cl];
+    }
+    if (pass == 0) {
+      __syncthreads();
+      if (cl == 0)
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) red[pg][k][0] = ab[k];
+      __syncthreads();
+      if (tid < MAXC)
+        part[(size_t)blockIdx.x * MAXC * (Cp + 1) + tid * (Cp + 1) + Cp] =
+            red[0][tid][0] + red[1][tid][0] + red[2][tid][0] + red[3][tid][0];
+    }
+  }
+}
+
+__global__ void head_bwd_finalize_kernel(const float* __restrict__ part, int NB, int Cp, int C, int ncls,
+                                         float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncls * (C + 1)) return;
+  const int k = i / (C + 1), c = i - k * (C + 1);
+  const int col = (c == C) ? Cp : c;
+  double s = 0.0;
+  for (int b = 0; b < NB; ++b) s += (double)part[(size_t)b * MAXC * (Cp + 1) + k * (Cp + 1) + col];
+  if (c == C) db[k] = (float)s;
+  else dw[(size_t)k * C + c] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss partials per block: [0]=sum w*nll, [1]=sum w, then I[MAXC], Sp[MAXC], Sg[MAXC]
+constexpr int LP = 2 + 3 * MAXC;
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ logits,
+                                                       const long long* __restrict__ labels,
+                                                       const float* __restrict__ cw, long P, long HW, int C,
+                                                       int ignore_index, float* __restrict__ part) {
+  __shared__ float sh[4];
+  float acc[LP];
+#pragma unroll
+  for (int i = 0; i < LP; ++i) acc[i] = 0.f;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    const long b = p / HW, r = p - b * HW;
+    float l[MAXC], raw[MAXC], m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      raw[k] = (k < C) ? logits[(b * C + k) * HW + r] : -INFINITY;
+      m = fmaxf(m, raw[k]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      l[k] = (k < C) ? expf(raw[k] - m) : 0.f;
+      se += l[k];
+    }
+    const float inv = 1.f / se, lse = logf(se);
+    const long long y = labels[p];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const float pk = l[k] * inv;
+      const float oh = (y == k) ? 1.f : 0.f;
+      acc[2 + k] += pk * oh;
+      acc[2 + MAXC + k] += pk;
+      acc[2 + 2 * MAXC + k] += oh;
+      if (y == k && k < C && y != ignore_index) {
+        const float wy = cw ? cw[k] : 1.f;
+        acc[0] += wy * (lse - (raw[k] - m));   // -log softmax = log(sum exp) - (logit - max)
+        acc[1] += wy;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LP; ++i) {
+    const float s = block_sum(acc[i], sh);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * LP + i] = s;
+  }
+}
+
+// state: [0]=loss [1]=ce [2]=dice(-mean dc) [3]=ce_den, [4..4+MAXC) dc, [.. ) den_raw(Sp+Sg+smooth), [..) a_k
+constexpr int LS = 4 + 3 * MAXC;
+__global__ void loss_finalize_kernel(const float* __restrict__ part, int NB, int C, const float* cw, int ignore_index,
+                                     float smooth, float dice_weight, float ce_weight, float* __restrict__ state) {
+  __shared__ double tot[LP];
+  const int t = threadIdx.x;
+  if (t < LP) {
+    double s = 0.0;
+    for (int b = 0; b < NB; ++b) s += (double)part[(size_t)b * LP + t];
+    tot[t] = s;
+  }
+  __syncthreads();
+  if (t != 0) return;
+  const double ce = tot[1] > 0.0 ? tot[0] / tot[1] : NAN;   // all pixels ignored -> NaN like torch
+  double wsum = 0.0, dsum = 0.0;
+  int nvalid = 0;
+  for (int k = 0; k < C; ++k) {
+    const double den_raw = tot[2 + MAXC + k] + tot[2 + 2 * MAXC + k] + (double)smooth;
+    const double den = den_raw < 1e-8 ? 1e-8 : den_raw;
+    const double dc = (2.0 * tot[2 + k] + (double)smooth) / den;
+    state[4 + k] = (float)dc;
+    state[4 + MAXC + k] = (float)den_raw;
+    const bool valid = !(ignore_index >= 0 && ignore_index < C && k == ignore_index);
+    if (valid) {
+      const double wk = cw ? (double)cw[k] : 1.0;
+      wsum += wk; dsum += dc * wk; ++nvalid;
+    }
+  }
+  if (cw && wsum < 1e-8) wsum = 1e-8;
+  const double dice = -(dsum / wsum);
+  for (int k = 0; k < C; ++k) {
+    const bool valid = !(ignore_index >= 0 && ignore_index < C && k == ignore_index);
+    state[4 + 2 * MAXC + k] = valid ? (float)((cw ? (double)cw[k] : 1.0) / wsum) : 0.f;
+  }
+  state[0] = (float)((double)dice_weight * dice + (double)ce_weight * ce);
+  state[1] = (float)ce;
+  state[2] = (float)dice;
+  state[3] = (float)tot[1];
+  (void)nvalid;
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits,
+                                                       const long long* __restrict__ labels,
+                                                       const float* __restrict__ cw, const float* __restrict__ state,
+                                                       const float* __restrict__ gout, long P, long HW, int C,
+                                                       int ignore_index, float dice_weight, float ce_weight,
+                                                       float* __restrict__ dlogits) {
+  const float go = gout[0];
+  const float ce_den = state[3];
+  float G0[MAXC], G1[MAXC];   // dL_dice/dp_k = G0 + onehot*G1
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    G0[k] = 0.f; G1[k] = 0.f;
+    if (k < C) {
+      const float dc = state[4 + k], den_raw = state[4 + MAXC + k], ak = state[4 + 2 * MAXC + k];
+      if (den_raw < 1e-8f) { G1[k] = -ak * 2.f / 1e-8f; }           // clip active: denominator constant
+      else { G0[k] = ak * dc / den_raw; G1[k] = -ak * 2.f / den_raw; }
+    }
+  }
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    const long b = p / HW, r = p - b * HW;
+    float l[MAXC], m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      l[k] = (k < C) ? logits[(b * C + k) * HW + r] : -INFINITY;
+      m = fmaxf(m, l[k]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) { l[k] = (k < C) ? expf(l[k] - m) : 0.f; se += l[k]; }
+    const float inv = 1.f / se;
+    const long long y = labels[p];
+    const bool ce_valid = (y >= 0 && y < C && y != ignore_index);
+    float wy = 0.f;
+    if (ce_valid) wy = (cw ? cw[y] : 1.f) / ce_den;
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      l[k] *= inv;
+      dot += l[k] * (G0[k] + ((y == k) ? G1[k] : 0.f));
+    }
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k)
+      if (k < C) {
+        const float gk = G0[k] + ((y == k) ? G1[k] : 0.f);
+        const float dd = l[k] * (gk - dot);
+        const float dce = wy * (l[k] - ((y == k) ? 1.f : 0.f));
+        dlogits[(b * C + k) * HW + r] = go * (dice_weight * dd + ce_weight * dce);
+      }
+  }
+}
+
+// confusion matrix M[pred][label] (uint64) over [N][C][HW] logits; argmax = FIRST maximum (torch.argmax)
+__global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict__ logits,
+                                                        const long long* __restrict__ labels, long P, long HW, int C,
+                                                        unsigned long long* __restrict__ M) {
+  __shared__ unsigned int hist[MAXC * MAXC];
+  if (threadIdx.x < MAXC * MAXC) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    const long b = p / HW, r = p - b * HW;
+    int best = 0;
+    float bv = logits[(b * C) * HW + r];
+    for (int k = 1; k < C; ++k) {
+      const float v = logits[(b * C + k) * HW + r];
+      if (v > bv || (v != v && bv == bv)) { bv = v; best = k; }   // NaN counts as maximal, like torch
+    }
+    const long long y = labels[p];
+    if (y >= 0 && y < C) atomicAdd(&hist[best * MAXC + (int)y], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < MAXC * MAXC && hist[threadIdx.x])
+    atomicAdd(&M[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+}  // namespace
+
+template <typename T> static size_t head_lds() { return (size_t)HT * (HCH * ET<T>::ES + 16); }
+static bool raise_lds(const void* f) {
+  return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
+int segk_head_blocks(long P) {
+  long g = (P + HT - 1) / HT;
+  return (int)(g > 512 ? 512 : g);
+}
+int segk_head_part_floats(long P, int Cp) { return segk_head_blocks(P) * MAXC * (Cp + 1); }
+
+int segk_head_fwd_impl(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp,
+                       int C, int ncls, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(y && w && bias && logits && B > 0 && H > 0 && W > 0, "head_fwd: bad arguments");
+  SEGK_REQUIRE(ncls >= 1 && ncls <= MAXC, "head_fwd: 1..%d classes supported, got %d", MAXC, ncls);
+  SEGK_REQUIRE(Cp % 32 == 0 && C > 0 && C <= Cp, "head_fwd: bad channels");
+  const long P = (long)B * H * W, HW = (long)H * W;
+  long g = (P + HT - 1) / HT;
+  if (g > 4096) g = 4096;
+  if (dtype == SEGK_DT_BF16)
+    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3((int)g), dim3(256), head_lds<bf16_t>(), st, (const bf16_t*)y, w, bias, logits, P, HW, Cp, C, ncls);
+  else {
+    SEGK_REQUIRE(raise_lds((const void*)head_fwd_kernel<float>), "head_fwd: cannot raise dynamic LDS limit");
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((int)g), dim3(256), head_lds<float>(), st, (const float*)y, w, bias, logits, P, HW, Cp, C, ncls);
+  }
+  SEGK_CHECK_LAUNCH("head_fwd");
+  return 0;
+}
+
+int segk_head_bwd_impl(const float* dlog, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
+                       int B, int H, int W, int Cp, int C, int ncls, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(dlog && y && w && dy && part && dw && db && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
+  SEGK_REQUIRE(ncls >= 1 && ncls <= MAXC && Cp % 32 == 0 && C > 0 && C <= Cp, "head_bwd: bad channels/classes");
+  const long P = (long)B * H * W, HW = (long)H * W;
+  const int nb = segk_head_blocks(P);
+  if (dtype == SEGK_DT_BF16)
+    hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), head_lds<bf16_t>(), st, dlog, (const bf16_t*)y, w, (bf16_t*)dy, part, P, HW, Cp, C, ncls);
+  else {
+    SEGK_REQUIRE(raise_lds((const void*)head_bwd_kernel<float>), "head_bwd: cannot raise dynamic LDS limit");
+    hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(nb), dim3(256), head_lds<float>(), st, dlog, (const float*)y, w, (float*)dy, part, P, HW, Cp, C, ncls);
+  }
+  SEGK_CHECK_LAUNCH("head_bwd");
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(ncls * (C + 1), 256)), dim3(256), 0, st, part, nb, Cp, C, ncls, dw, db);
+  SEGK_CHECK_LAUNCH("head_bwd_finalize");
+  return 0;
+}
+
+int segk_loss_blocks(long P) {
+  long g = (P + 255) / 256;
+  return (int)(g > 1024 ? 1024 : g);
+}
+int segk_loss_part_floats(long P) { return segk_loss_blocks(P) * LP; }
+int segk_loss_state_floats(void) { return LS; }
+
+int segk_loss_fwd_impl(const float* logits, const long long* labels, const float* cw, int N, int C, long HW,
+                       int ignore_index, float smooth, float dice_weight, float ce_weight, float* part, float* state,
+                       hipStream_t st) {
+  SEGK_REQUIRE(logits && labels && part && state && N > 0 && HW > 0, "loss_fwd: bad arguments");
+  SEGK_REQUIRE(C >= 1 && C <= MAXC, "loss_fwd: 1..%d classes supported, got %d", MAXC, C);
+  const long P = (long)N * HW;
+  const int nb = segk_loss_blocks(P);
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part);
+  SEGK_CHECK_LAUNCH("loss_fwd");
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, part, nb, C, cw, ignore_index, smooth, dice_weight, ce_weight, state);
+  SEGK_CHECK_LAUNCH("loss_finalize");
+  return 0;
+}
+
+int segk_loss_bwd_impl(const float* logits, const long long* labels, const float* cw, const float* state,
+                       const float* gout, int N, int C, long HW, int ignore_index, float dice_weight, float ce_weight,
+                       float* dlogits, hipStream_t st) {
+  SEGK_REQUIRE(logits && labels && state && gout && dlogits && N > 0 && HW > 0 && C >= 1 && C <= MAXC, "loss_bwd: bad arguments");
+  const long P = (long)N * HW;
+  long g = (P + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)g), dim3(256), 0, st, logits, labels, cw, state, gout, P, HW, C, ignore_index, dice_weight, ce_weight, dlogits);
+  SEGK_CHECK_LAUNCH("loss_bwd");
+  return 0;
+}
+
+int segk_confusion_impl(const float* logits, const long long* labels, int N, int C, long HW, unsigned long long* M,
+                        hipStream_t st) {
+  SEGK_REQUIRE(logits && labels && M && N > 0 && HW > 0 && C >= 1 && C <= MAXC, "confusion: bad arguments");
+  const long P = (long)N * HW;
+  long g = (P + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(confusion_kernel, dim3((int)g), dim3(256), 0, st, logits, labels, P, HW, C, M);
+  SEGK_CHECK_LAUNCH("confusion");
+  return 0;
+}

@@ -1,0 +1,35 @@
+// Internal (non-ABI) declarations shared between the kernel translation units and api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct ConvArgs {
+  const void* srcA;     // NHWC [B,H,W,CA]  (un-shuffle gather: [B,2H,2W,CA])
+  const void* srcB;     // optional second source [B,H,W,CB] (channel concat without a concat)
+  const void* w;        // packed weights [K/CH][taps][Ntot][CH]
+  const float* bias;    // optional per-N bias
+  const float* scale;   // optional BN+ReLU prologue (per input channel)
+  const float* shift;
+  void* out;            // [B,H,W,CO1]  (pixel-shuffle: [B,2H,2W,CO1])
+  void* out2;           // optional second destination [B,H,W,CO2]
+  float* stats;         // optional [tiles][Ntot][2] BN partial sums
+  int B, H, W;
+  int CA, CB;
+  int Ntot, CO1, CO2;
+  int twl, tiles_x, tiles_y;
+  int unshuf, shuffle;
+};
+int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st);
+
+struct WgradArgs {
+  const void* dz;       // NHWC [B,H,W,CD]        (un-shifted operand; rows of dW)
+  const void* srcA;     // NHWC [B,H,W,CA]        (tap-shifted operand; columns of dW)
+  const void* srcB;     // optional second source [B,H,W,CB]
+  const float* scale;   // optional BN+ReLU prologue on the shifted operand
+  const float* shift;
+  float* slabs;         // [S][CD][taps][CA+CB] fp32 partial weight gradients
+  int B, H, W;          // grid of the un-shifted operand
+  int CD, CA, CB;
+  int S;                // split-K factor over spatial tiles
+};
+int segk_wgrad_launch(const WgradArgs& a, int geo, int dtype, hipStream_t st);

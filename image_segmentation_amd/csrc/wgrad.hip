@@ -1,0 +1,282 @@
+// Weight-gradient kernels on CDNA4 matrix cores for NHWC activations (gfx950).
+//
+//   dW[n][tap][k] = sum over pixels p of  dz[p][n] * a[p + offset(tap)][k]
+//
+//   GEO 0 : Conv2d 3x3 pad 1   (reference unet/unet.py:16,19; clip/clipunet.py:87,90)   9 taps, halo 1
+//   GEO 1 : Conv2d 1x1         (clip/clipunet.py:84,122)                                1 tap
+//   GEO 2 : ConvTranspose2d(k=2,s=2) (unet.py:59, clipunet.py:83): dz := layer input (coarse grid),
+//           a := output gradient on the 2x fine grid, taps (a,c) at stride 2                4 taps
+//
+// The contraction index is the PIXEL, while NHWC keeps channels contiguous, so both MFMA operands are
+// "k-strided".  bf16: tiles are staged in their natural [pixel][32 channels] form (64-byte rows, one LDS
+// region per 32-channel block) and fragments are fetched with the gfx950 transposing LDS read
+// ds_read_b64_tr_b16, which hands each lane 4 consecutive pixels of one channel: two reads make one
+// 32x32x16 operand.  Tap shifts are pixel-row address shifts of the same staged patch (no im2col).
+// fp32: exact 32x32x2 MFMA, one ds_read_b32 per operand (lanes = 32 contiguous channels).
+// Each wave owns a 32x32 (n,k) block for ALL taps (9 accumulators); split-K over spatial tiles writes
+// fp32 slabs that segk_wgrad_reduce sums in fixed order (bit-stable, no atomics).
+#include "common.hpp"
+#include "segk_internal.h"
+#include "../../include/segk.h"
+
+namespace {
+
+template <typename T, int GEO> struct WG {
+  static constexpr bool BF = (sizeof(T) == 2);
+  static constexpr int R = (GEO == 2) ? (BF ? 4 : 2) : (BF ? 8 : 4);   // dz rows per tile (16 px wide)
+  static constexpr int NTAPS = GEO == 0 ? 9 : (GEO == 1 ? 1 : 4);
+  static constexpr int PH = GEO == 0 ? R + 2 : (GEO == 1 ? R : 2 * R);
+  static constexpr int PW = GEO == 0 ? 18 : (GEO == 1 ? 16 : 32);
+  static constexpr int BLKP = 32 * (int)sizeof(T);   // bytes of one pixel inside a 32-channel block
+  static constexpr int PPB = BLKP / 16;             // 16-byte pieces per pixel per block
+  static constexpr int NDZ = R * 16;                // dz pixels per tile
+  static constexpr int NPP = PH * PW;               // patch pixels per tile
+};
+
+__device__ __forceinline__ int tap_pixel(int geo, int tap, int r, int x) {
+  // patch-pixel index of dz pixel (r, x) under tap
+  if (geo == 0) return (r + tap / 3) * 18 + x + tap % 3;
+  if (geo == 1) return r * 16 + x;
+  return (2 * r + (tap >> 1)) * 32 + 2 * x + (tap & 1);
+}
+
+template <typename T, int GEO, int WC, int WI>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(const WgradArgs a) {
+  using G = WG<T, GEO>;
+  using E = ET<T>;
+  constexpr int R = G::R, NTAPS = G::NTAPS, BLKP = G::BLKP, PPB = G::PPB;
+  constexpr int DZ_PIECES = G::NDZ * WC * PPB, PA_PIECES = G::NPP * WI * PPB;
+  constexpr int NDL = (DZ_PIECES + 255) / 256, NPL = (PA_PIECES + 255) / 256;
+  constexpr int DZ_BYTES = WC * G::NDZ * BLKP;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const dzs = smem;
+  char* const pas = smem + DZ_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, W = a.W;
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + R - 1) / R;
+  const int ntiles = a.B * tiles_y * tiles_x;
+
+  const int KT = (a.CA + a.CB) / (32 * WI), NCT = (a.CD / (32 * WC)) * KT;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int s = lid / NCT, ct = lid - s * NCT;
+  const int n0 = (ct / KT) * 32 * WC, k0 = (ct % KT) * 32 * WI;
+
+  const T* src; int SC, kc0;                      // shifted-operand source of this k-tile
+  if (k0 < a.CA) { src = (const T*)a.srcA; SC = a.CA; kc0 = k0; }
+  else { src = (const T*)a.srcB; SC = a.CB; kc0 = k0 - a.CA; }
+  const bool pro = (a.scale != nullptr);
+  const int FH = GEO == 2 ? 2 * H : H, FW = GEO == 2 ? 2 * W : W;   // grid of the shifted operand
+
+  // tile-invariant piece decomposition: 256 % (W?*PPB) == 0, so a thread's channel slot is fixed
+  static_assert(256 % (WC * PPB) == 0 && 256 % (WI * PPB) == 0, "channel slot must be thread-invariant");
+  const int dcc = tid % (WC * PPB), pcc = tid % (WI * PPB);
+  int d_pix[NDL], p_pix[NPL];
+#pragma unroll
+  for (int i = 0; i < NDL; ++i) {
+    const int q = tid + i * 256;
+    d_pix[i] = q < DZ_PIECES ? q / (WC * PPB) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int q = tid + i * 256;
+    p_pix[i] = q < PA_PIECES ? q / (WI * PPB) : -1;
+  }
+  float psc[E::VEC], psh[E::VEC];
+  if (pro) {
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) {
+      psc[j] = a.scale[kc0 + pcc * E::VEC + j];
+      psh[j] = a.shift[kc0 + pcc * E::VEC + j];
+    }
+  }
+
+  uint4 dreg[NDL], preg[NPL];
+  bool pok[NPL];
+  auto prefetch = [&](int t) {
+    const int b = t / (tiles_y * tiles_x);
+    const int rem = t - b * tiles_y * tiles_x;
+    const int y0 = (rem / tiles_x) * R, x0 = (rem % tiles_x) * 16;
+#pragma unroll
+    for (int i = 0; i < NDL; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);   // out-of-image pixels contribute zeros
+      if (d_pix[i] >= 0) {
+        const int gy = y0 + (d_pix[i] >> 4), gx = x0 + (d_pix[i] & 15);
+        if (gy < H && gx < W)
+          v = *(const uint4*)((const T*)a.dz + ((size_t)(b * H + gy) * W + gx) * a.CD + n0 + dcc * E::VEC);
+      }
+      dreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      pok[i] = false;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (p_pix[i] >= 0) {
+        const int py = p_pix[i] / G::PW, px = p_pix[i] - py * G::PW;
+        int gy, gx;
+        if (GEO == 0) { gy = y0 + py - 1; gx = x0 + px - 1; }
+        else if (GEO == 1) { gy = y0 + py; gx = x0 + px; }
+        else { gy = 2 * y0 + py; gx = 2 * x0 + px; }
+        if (gy >= 0 && gy < FH && gx >= 0 && gx < FW) {
+          pok[i] = true;
+          v = *(const uint4*)(src + ((size_t)(b * FH + gy) * FW + gx) * SC + kc0 + pcc * E::VEC);
+        }
+      }
+      preg[i] = v;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NDL; ++i)
+      if (d_pix[i] >= 0) {
+        const int blk = dcc / PPB, c16 = dcc - blk * PPB;
+        *(uint4*)(dzs + blk * (G::NDZ * BLKP) + d_pix[i] * BLKP + c16 * 16) = dreg[i];
+      }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+      if (p_pix[i] >= 0) {
+        const int blk = pcc / PPB, c16 = pcc - blk * PPB;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (pok[i]) {
+          v = preg[i];
+          if (pro) {
+            float f[E::VEC];
+            unpack16<T>(v, f);
+#pragma unroll
+            for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
+            v = pack16<T>(f);
+          }
+        }
+        *(uint4*)(pas + blk * (G::NPP * BLKP) + p_pix[i] * BLKP + c16 * 16) = v;
+      }
+  };
+
+  const bool computes = wave < WC * WI;
+  const int wc = wave / WI, wi = wave - wc * WI;
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const char* const dzb = dzs + wc * (G::NDZ * BLKP);
+  const char* const pab = pas + wi * (G::NPP * BLKP);
+
+  int t = s;
+  if (t < ntiles) prefetch(t);
+  for (; t < ntiles; t += a.S) {
+    stage();
+    __syncthreads();
+    if (t + a.S < ntiles) prefetch(t + a.S);
+    if (computes) {
+      if constexpr (G::BF) {
+        // lane -> (group g: channel half gsub, k half h; q = pixel row of the 4x16 block, p = 4-col piece)
+        const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+        const int gsub = g & 1, h = g >> 1;
+        const int coff = (16 * gsub + 4 * p) * 2;
+        typedef __attribute__((address_space(3))) s16x4* lds_v4;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int xa = 8 * h + q;   // pixel column of read 0; read 1 is +4
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(dzb + (r * 16 + xa) * BLKP + coff));
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(dzb + (r * 16 + xa + 4) * BLKP + coff));
+          const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int tp = 0; tp < NTAPS; ++tp) {
+            const int p0 = tap_pixel(GEO, tp, r, xa), p1 = tap_pixel(GEO, tp, r, xa + 4);
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pab + p0 * BLKP + coff));
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pab + p1 * BLKP + coff));
+            const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tp], 0, 0, 0);
+          }
+        }
+      } else {
+        const int i32 = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+          for (int kp = 0; kp < 8; ++kp) {
+            const int x = 2 * kp + h;
+            const float fa = *(const float*)(dzb + (r * 16 + x) * BLKP + i32 * 4);
+#pragma unroll
+            for (int tp = 0; tp < NTAPS; ++tp) {
+              const float fb = *(const float*)(pab + tap_pixel(GEO, tp, r, x) * BLKP + i32 * 4);
+              acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[tp], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (computes) {
+    const int K = a.CA + a.CB;
+    const int col = lane & 31, lh = lane >> 5;
+    float* const slab = a.slabs + (size_t)s * a.CD * NTAPS * K;
+#pragma unroll
+    for (int tp = 0; tp < NTAPS; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        slab[((size_t)(n0 + wc * 32 + row) * NTAPS + tp) * K + k0 + wi * 32 + col] = acc[tp][r];
+      }
+  }
+}
+
+template <typename T, int GEO, int WC, int WI>
+int launch_cfg(const WgradArgs& a, hipStream_t st) {
+  using G = WG<T, GEO>;
+  const size_t lds = (size_t)WC * G::NDZ * G::BLKP + (size_t)WI * G::NPP * G::BLKP;
+  const int NCT = (a.CD / (32 * WC)) * ((a.CA + a.CB) / (32 * WI));
+  auto kern = wgrad_kernel<T, GEO, WC, WI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SEGK_FAIL(-3, "wgrad: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3(256), lds, st, a);
+  SEGK_CHECK_LAUNCH("wgrad");
+  return 0;
+}
+
+template <typename T, int GEO>
+int launch_geo(const WgradArgs& a, hipStream_t st) {
+  const bool wc2 = a.CD % 64 == 0;
+  const bool wi2 = a.CA % 64 == 0 && a.CB % 64 == 0;
+  if (wc2 && wi2) return launch_cfg<T, GEO, 2, 2>(a, st);
+  if (wc2) return launch_cfg<T, GEO, 2, 1>(a, st);
+  if (wi2) return launch_cfg<T, GEO, 1, 2>(a, st);
+  return launch_cfg<T, GEO, 1, 1>(a, st);
+}
+
+template <typename T>
+int launch_t(const WgradArgs& a, int geo, hipStream_t st) {
+  if (geo == 0) return launch_geo<T, 0>(a, st);
+  if (geo == 1) return launch_geo<T, 1>(a, st);
+  return launch_geo<T, 2>(a, st);
+}
+
+}  // namespace
+
+int segk_wgrad_tiles(int B, int H, int W, int geo, int dtype) {
+  const bool bf = dtype == SEGK_DT_BF16;
+  const int R = geo == 2 ? (bf ? 4 : 2) : (bf ? 8 : 4);
+  return B * cdiv(H, R) * cdiv(W, 16);
+}
+
+int segk_wgrad_launch(const WgradArgs& a, int geo, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "wgrad: bad dtype %d", dtype);
+  SEGK_REQUIRE(geo >= 0 && geo <= 2, "wgrad: bad geometry %d", geo);
+  SEGK_REQUIRE(a.dz && a.srcA && a.slabs, "wgrad: null pointer");
+  SEGK_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, "wgrad: bad shape");
+  SEGK_REQUIRE(a.CD > 0 && a.CD % 32 == 0 && a.CA > 0 && a.CA % 32 == 0 && a.CB >= 0 && a.CB % 32 == 0,
+               "wgrad: channel counts must be multiples of 32 (CD=%d CA=%d CB=%d)", a.CD, a.CA, a.CB);
+  SEGK_REQUIRE((a.CB == 0) == (a.srcB == nullptr), "wgrad: second source mismatch");
+  SEGK_REQUIRE(!(a.scale && a.CB) && ((a.scale == nullptr) == (a.shift == nullptr)), "wgrad: bad BN prologue");
+  SEGK_REQUIRE(a.S >= 1 && a.S <= 65535, "wgrad: bad split-K factor %d", a.S);
+  SEGK_REQUIRE((long long)a.B * a.H * a.W * 4 < 2147483647LL, "wgrad: pixel index overflows int32");
+  return dtype == SEGK_DT_BF16 ? launch_t<bf16_t>(a, geo, st) : launch_t<float>(a, geo, st);
+}

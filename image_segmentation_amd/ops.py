@@ -1,0 +1,554 @@
+"""Host side of the fused segmentation ops: torch.autograd.Functions that drive the HIP kernels of
+libsegk.so through the C ABI (include/segk.h).  PyTorch is used for device memory (caching allocator),
+streams and autograd bookkeeping only -- every FLOP and byte of the hot path runs in the hand-written
+kernels.  There is no CPU / eager fallback: non-CUDA tensors raise.
+
+Activation convention ("act tensor"): logical shape [B,C,H,W] (what the reference's nn.Modules exchange)
+backed by an NHWC buffer [B,H,W,Cp] with Cp = C rounded up to 32 and zero padding channels, in the compute
+dtype (fp32 = parity mode, bf16 = performance mode).  For C % 32 == 0 this is exactly torch's
+channels_last memory format.
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+_compute_dtype = torch.bfloat16
+
+
+def set_compute_dtype(dtype):
+    """torch.float32: exact-fp32 MFMA kernels (parity gate: logits within 1e-3 of the CPU reference);
+    torch.bfloat16: bf16 storage + bf16 MFMA with fp32 accumulation and fp32 BatchNorm statistics."""
+    global _compute_dtype
+    if dtype not in _DT:
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _compute_dtype = dtype
+
+
+def get_compute_dtype():
+    return _compute_dtype
+
+
+def pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: expected a CUDA/HIP tensor -- image_segmentation_amd has no CPU path "
+                           "(the CPU oracle lives in oracle/ and is test infrastructure only)")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# act-tensor helpers
+def new_act(B, C, H, W, dtype, device):
+    """Allocate an act tensor; padding channels are zeroed only when they exist."""
+    Cp = pad32(C)
+    buf = torch.empty((B, H, W, Cp), dtype=dtype, device=device)
+    if Cp != C:
+        buf[..., C:].zero_()
+    return buf.permute(0, 3, 1, 2)[:, :C]
+
+
+def act_view(buf, C):
+    return buf.permute(0, 3, 1, 2)[:, :C]
+
+
+def act_info(t, dtype):
+    """Return (data_ptr, Cp) if `t` already is an act tensor of `dtype`, else None."""
+    if t.dim() != 4 or t.dtype != dtype or not t.is_cuda:
+        return None
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    Cp = sw if W > 1 else (sh if H > 1 else pad32(C))
+    if sc != 1 or Cp < C or Cp % 32 != 0 or Cp != pad32(C):
+        return None
+    if (W > 1 and sw != Cp) or (H > 1 and sh != W * Cp) or (B > 1 and sb != H * W * Cp):
+        return None
+    if (t.storage_offset() * t.element_size()) % 16 != 0:
+        return None
+    return t.data_ptr(), Cp
+
+
+def to_act(x, dtype):
+    """Convert any [B,C,H,W] CUDA tensor to an act tensor (zero-copy when it already is one)."""
+    _require_cuda(x, "to_act")
+    if act_info(x, dtype) is not None:
+        return x
+    B, C, H, W = x.shape
+    src = x.detach()
+    if src.dtype != torch.float32 or not src.is_contiguous():
+        src = src.float().contiguous()       # layout/dtype normalisation of a foreign tensor (edge only)
+    out = torch.empty((B, H, W, pad32(C)), dtype=dtype, device=x.device)
+    _lib.call("segk_nchw_to_nhwc", src.data_ptr(), out.data_ptr(), B, C, H, W, pad32(C), _DT[dtype], _stream())
+    return act_view(out, C)
+
+
+def act_to_nchw(t):
+    """act tensor -> contiguous NCHW fp32 (what the reference modules would return)."""
+    info = act_info(t, t.dtype)
+    if info is None:
+        return t.float().contiguous()
+    B, C, H, W = t.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=t.device)
+    _lib.call("segk_nhwc_to_nchw", info[0], out.data_ptr(), B, C, H, W, info[1], _DT[t.dtype], _stream())
+    return out
+
+
+def _raw(t, dtype):
+    """(ptr, Cp) of an act tensor, converting if needed; returns (tensor_kept_alive, ptr, Cp)."""
+    t = to_act(t, dtype)
+    ptr, Cp = act_info(t, dtype)
+    return t, ptr, Cp
+
+
+# ------------------------------------------------------------------------------------------------
+# packed-weight cache (parameters stay fp32 OIHW/IOHW: the source of truth for state_dict/optimizer)
+class PackCache:
+    """Re-packs a parameter into the MFMA layout only when its autograd version counter moved."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, key, param, builder):
+        ver = (param._version, param.data_ptr(), param.device)
+        hit = self._c.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, builder())
+            self._c[key] = hit
+        return hit[1]
+
+
+def pack_conv(w, CA, CB, dtype, mode, taps=9):
+    Cout = w.shape[0]
+    Coutp, CAp, CBp = pad32(Cout), pad32(CA), (pad32(CB) if CB else 0)
+    dst = torch.empty(((CAp + CBp) * taps * Coutp,), dtype=dtype, device=w.device)
+    wf = w.detach()
+    if wf.dtype != torch.float32 or not wf.is_contiguous():
+        wf = wf.float().contiguous()
+    _lib.call("segk_pack_conv_weight", wf.data_ptr(), dst.data_ptr(), Cout, CA, CB, Coutp, CAp, CBp, taps, mode,
+              _DT[dtype], _stream())
+    return dst
+
+
+def pack_convt(w, dtype, mode):
+    Cin, Cout = w.shape[0], w.shape[1]
+    dst = torch.empty((pad32(Cin) * 4 * pad32(Cout),), dtype=dtype, device=w.device)
+    wf = w.detach()
+    if wf.dtype != torch.float32 or not wf.is_contiguous():
+        wf = wf.float().contiguous()
+    _lib.call("segk_pack_convt_weight", wf.data_ptr(), dst.data_ptr(), Cin, Cout, pad32(Cin), pad32(Cout), mode,
+              _DT[dtype], _stream())
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers over the C ABI (all asynchronous on the current stream)
+def _f32(n, dev):
+    return torch.empty((n,), dtype=torch.float32, device=dev)
+
+
+def conv3x3(srcA, ptrA, CAp, ptrB, CBp, wpacked, out_ptr, CO1p, out2_ptr, CO2p, B, H, W, dtype, scale=None,
+            shift=None, stats=None):
+    _lib.call("segk_conv3x3", ptrA, ptrB, wpacked.data_ptr(), 0, _p(scale), _p(shift), out_ptr, out2_ptr, _p(stats),
+              B, H, W, CAp, CBp, CO1p, CO2p, _DT[dtype], _stream())
+
+
+def wgrad(dz_ptr, CDp, ptrA, CAp, ptrB, CBp, B, H, W, geo, dtype, dev, scale=None, shift=None):
+    """Returns the slabs tensor and S (split-K factor)."""
+    taps = {0: 9, 1: 1, 2: 4}[geo]
+    tiles = _lib.query("segk_wgrad_tiles", B, H, W, geo, _DT[dtype])
+    wc = 2 if CDp % 64 == 0 else 1
+    wi = 2 if (CAp % 64 == 0 and CBp % 64 == 0) else 1
+    nct = (CDp // (32 * wc)) * ((CAp + CBp) // (32 * wi))
+    S = max(1, min(tiles, 1024 // nct if nct < 1024 else 1))
+    slabs = _f32(S * CDp * taps * (CAp + CBp), dev)
+    _lib.call("segk_wgrad", dz_ptr, ptrA, ptrB, _p(scale), _p(shift), slabs.data_ptr(), S, B, H, W, CDp, CAp, CBp,
+              geo, _DT[dtype], _stream())
+    return slabs, S
+
+
+def wgrad_to_param(slabs, S, shape, N, CA, CB, taps, dev):
+    grad = torch.empty(shape, dtype=torch.float32, device=dev)
+    _lib.call("segk_wgrad_reduce", slabs.data_ptr(), S, grad.data_ptr(), N, CA, CB, pad32(N), pad32(CA),
+              pad32(CB) if CB else 0, taps, _stream())
+    return grad
+
+
+def bn_finalize(stats, tiles, C, count, conv_bias, bn_w, bn_b, rmean, rvar, momentum, eps, training, dev):
+    Cp = pad32(C)
+    scale, shift = _f32(Cp, dev), _f32(Cp, dev)
+    mean, rstd = _f32(Cp, dev), _f32(Cp, dev)
+    _lib.call("segk_bn_finalize", _p(stats), tiles, Cp, C, float(count), _p(conv_bias), bn_w.data_ptr(),
+              bn_b.data_ptr(), _p(rmean), _p(rvar), float(momentum), float(eps), int(training), scale.data_ptr(),
+              shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream())
+    return scale, shift, mean, rstd
+
+
+def bn_relu_bwd(dy_ptr, z_ptr, dz_ptr, scale, shift, mean, rstd, P, C, dtype, dev):
+    Cp = pad32(C)
+    nb = _lib.query("segk_bn_bwd_blocks", P, Cp, _DT[dtype])
+    part, coef = _f32(nb * Cp * 2, dev), _f32(2 * Cp, dev)
+    dgamma, dbeta = _f32(C, dev), _f32(C, dev)
+    _lib.call("segk_bn_relu_bwd", dy_ptr, z_ptr, dz_ptr, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), P, Cp, C, part.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(),
+              _DT[dtype], _stream())
+    return dgamma, dbeta
+
+
+def channel_sum(ptr, P, C, dtype, dev):
+    Cp = pad32(C)
+    nb = _lib.query("segk_bn_bwd_blocks", P, Cp, _DT[dtype])
+    part, out = _f32(nb * Cp, dev), _f32(C, dev)
+    _lib.call("segk_channel_sum", ptr, P, Cp, C, part.data_ptr(), out.data_ptr(), _DT[dtype], _stream())
+    return out
+
+
+def _param_f32(p):
+    t = p.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+class DoubleConvFn(torch.autograd.Function):
+    """y = ReLU(BN2(Conv3x3(ReLU(BN1(Conv3x3([xa | xb]))))))  -- reference unet/unet.py:4-25 (bias=True) and
+    clip/clipunet.py:86-93 (bias=False).  xb is the optional second concat operand (unet.py:63 /
+    clipunet.py:102), consumed without materialising the concat.
+
+    Forward kernels: conv3x3(+stats) -> bn_finalize -> conv3x3 with BN1+ReLU fused in its load prologue
+    (+stats) -> bn_finalize -> bn_relu_apply.  The conv biases never enter the kernels: ahead of a
+    training-mode BatchNorm they cancel (they only shift running_mean, handled in bn_finalize), and in
+    eval mode they fold into the BN shift.
+    """
+
+    @staticmethod
+    def forward(ctx, mod, xa, xb, w1, b1, g1, be1, w2, b2, g2, be2):
+        dtype = mod.compute_dtype or _compute_dtype
+        _require_cuda(xa, "DoubleConvReLU")
+        dev = xa.device
+        B, CA, H, W = xa.shape
+        CB = 0 if xb is None else xb.shape[1]
+        Cout = w1.shape[0]
+        Coutp = pad32(Cout)
+        training = mod.training
+        bn1, bn2 = mod.bn_modules()
+        xa_t, pA, CAp = _raw(xa, dtype)
+        xb_t, pB, CBp = (None, 0, 0) if xb is None else _raw(xb, dtype)
+        w1p = mod.cache.get(("w1f", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 0))
+        w2p = mod.cache.get(("w2f", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 0))
+        tiles = _lib.query("segk_conv_tiles", B, H, W)
+        P = B * H * W
+
+        z1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
+        st1 = _f32(tiles * Coutp * 2, dev) if training else None
+        conv3x3(xa_t, pA, CAp, pB, CBp, w1p, z1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, stats=st1)
+        mom1 = bn1.momentum if bn1.momentum is not None else 0.1
+        sc1, sh1, mu1, rs1 = bn_finalize(st1, tiles, Cout, P, None if b1 is None else _param_f32(b1), _param_f32(g1),
+                                         _param_f32(be1), bn1.running_mean, bn1.running_var, mom1, bn1.eps, training,
+                                         dev)
+        z2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
+        st2 = _f32(tiles * Coutp * 2, dev) if training else None
+        conv3x3(z1, z1.data_ptr(), Coutp, 0, 0, w2p, z2.data_ptr(), Coutp, 0, 0, B, H, W, dtype, scale=sc1, shift=sh1,
+                stats=st2)
+        mom2 = bn2.momentum if bn2.momentum is not None else 0.1
+        sc2, sh2, mu2, rs2 = bn_finalize(st2, tiles, Cout, P, None if b2 is None else _param_f32(b2), _param_f32(g2),
+                                         _param_f32(be2), bn2.running_mean, bn2.running_var, mom2, bn2.eps, training,
+                                         dev)
+        if training:
+            bn1.num_batches_tracked.add_(1)
+            bn2.num_batches_tracked.add_(1)
+        y = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
+        _lib.call("segk_bn_relu_apply", z2.data_ptr(), y.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), P, Coutp,
+                  _DT[dtype], _stream())
+
+        ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, CA, CB, Cout)
+        ctx.training = training
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.save_for_backward(xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2)
+        return act_view(y, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("DoubleConvReLU backward requires train() mode (batch-statistics BatchNorm)")
+        xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2 = ctx.saved_tensors
+        mod, dtype = ctx.mod, ctx.dtype
+        B, H, W, CA, CB, Cout = ctx.dims
+        dev = z1.device
+        Coutp, CAp, CBp = pad32(Cout), pad32(CA), (pad32(CB) if CB else 0)
+        P = B * H * W
+        dy_t, pdy, _ = _raw(dy, dtype)
+        pA = act_info(xa_t, dtype)[0]
+        pB = 0 if xb_t is None else act_info(xb_t, dtype)[0]
+
+        # ---- second conv: BN2+ReLU backward, data gradient, weight gradient
+        dz2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
+        dg2, dbe2 = bn_relu_bwd(pdy, z2.data_ptr(), dz2.data_ptr(), sc2, sh2, mu2, rs2, P, Cout, dtype, dev)
+        w2d = mod.cache.get(("w2d", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 1))
+        da1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
+        conv3x3(dz2, dz2.data_ptr(), Coutp, 0, 0, w2d, da1.data_ptr(), Coutp, 0, 0, B, H, W, dtype)
+        slabs, S = wgrad(dz2.data_ptr(), Coutp, z1.data_ptr(), Coutp, 0, 0, B, H, W, 0, dtype, dev, scale=sc1, shift=sh1)
+        dw2 = wgrad_to_param(slabs, S, w2.shape, Cout, Cout, 0, 9, dev)
+        del slabs, dz2
+
+        # ---- first conv (dz1 overwrites da1 in place: da1 is private to this function)
+        dg1, dbe1 = bn_relu_bwd(da1.data_ptr(), z1.data_ptr(), da1.data_ptr(), sc1, sh1, mu1, rs1, P, Cout, dtype, dev)
+        dz1 = da1
+        dxa = dxb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            w1d = mod.cache.get(("w1d", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 1))
+            dxa_buf = torch.empty((B, H, W, CAp), dtype=dtype, device=dev)
+            dxb_buf = torch.empty((B, H, W, CBp), dtype=dtype, device=dev) if CB else None
+            conv3x3(dz1, dz1.data_ptr(), Coutp, 0, 0, w1d, dxa_buf.data_ptr(), CAp, _p(dxb_buf), CBp, B, H, W, dtype)
+            dxa = act_view(dxa_buf, CA)
+            dxb = act_view(dxb_buf, CB) if CB else None
+        slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev)
+        dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev)
+        # conv biases ahead of a batch-statistics BatchNorm have an identically zero gradient
+        db1 = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_bias[0] else None
+        db2 = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_bias[1] else None
+        return None, dxa, dxb, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(2,2) -- reference unet/unet.py:40."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _require_cuda(x, "MaxPool2d")
+        x_t, px, Cp = _raw(x, dtype)
+        B, C, H, W = x.shape
+        y = torch.empty((B, H // 2, W // 2, Cp), dtype=dtype, device=x.device)
+        _lib.call("segk_maxpool2x2_fwd", px, y.data_ptr(), B, H, W, Cp, _DT[dtype], _stream())
+        ctx.save_for_backward(x_t)
+        ctx.dtype = dtype
+        return act_view(y, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x_t,) = ctx.saved_tensors
+        dtype = ctx.dtype
+        B, C, H, W = x_t.shape
+        px, Cp = act_info(x_t, dtype)
+        dy_t, pdy, _ = _raw(dy, dtype)
+        dx = torch.empty((B, H, W, Cp), dtype=dtype, device=x_t.device)
+        _lib.call("segk_maxpool2x2_bwd", px, pdy, dx.data_ptr(), B, H, W, Cp, 0, _DT[dtype], _stream())
+        return act_view(dx, C), None
+
+
+class ConvT2x2Fn(torch.autograd.Function):
+    """nn.ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) -- reference unet/unet.py:59, clip/clipunet.py:83.
+    Non-overlapping, so forward is one GEMM [P x Cin].[Cin x 4Cout] with a pixel-shuffle store."""
+
+    @staticmethod
+    def forward(ctx, mod, x, w, b):
+        dtype = mod.compute_dtype or _compute_dtype
+        _require_cuda(x, "ConvTranspose2d")
+        dev = x.device
+        B, Cin, H, W = x.shape
+        Cout = w.shape[1]
+        Cinp, Coutp = pad32(Cin), pad32(Cout)
+        x_t, px, _ = _raw(x, dtype)
+        wp = mod.cache.get(("tf", dtype), w, lambda: pack_convt(w, dtype, 0))
+
+        def bias4():
+            t = torch.zeros((4, Coutp), dtype=torch.float32, device=dev)
+            t[:, :Cout] = _param_f32(b)
+            return t
+        b4 = None if b is None else mod.cache.get(("tb", dtype), b, bias4)
+        out = torch.empty((B, 2 * H, 2 * W, Coutp), dtype=dtype, device=dev)
+        _lib.call("segk_convt2x2_fwd", px, wp.data_ptr(), _p(b4), out.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
+                  _stream())
+        ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, Cin, Cout)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x_t, w)
+        return act_view(out, Cout)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x_t, w = ctx.saved_tensors
+        mod, dtype = ctx.mod, ctx.dtype
+        B, H, W, Cin, Cout = ctx.dims
+        dev = x_t.device
+        Cinp, Coutp = pad32(Cin), pad32(Cout)
+        d_t, pd, _ = _raw(dout, dtype)
+        px = act_info(x_t, dtype)[0]
+        dx = None
+        if ctx.needs_input_grad[1]:
+            wd = mod.cache.get(("td", dtype), w, lambda: pack_convt(w, dtype, 1))
+            dxb = torch.empty((B, H, W, Cinp), dtype=dtype, device=dev)
+            _lib.call("segk_convt2x2_dgrad", pd, wd.data_ptr(), dxb.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
+                      _stream())
+            dx = act_view(dxb, Cin)
+        slabs, S = wgrad(px, Cinp, pd, Coutp, 0, 0, B, H, W, 2, dtype, dev)
+        dw = wgrad_to_param(slabs, S, w.shape, Cin, Cout, 0, 4, dev)
+        db = channel_sum(pd, B * 4 * H * W, Cout, dtype, dev) if ctx.has_bias else None
+        return None, dx, dw, db
+
+
+class Conv1x1Fn(torch.autograd.Function):
+    """nn.Conv2d(Cin, Cout, kernel_size=1) between act tensors -- reference clip/clipunet.py:84,122."""
+
+    @staticmethod
+    def forward(ctx, mod, x, w, b):
+        dtype = mod.compute_dtype or _compute_dtype
+        _require_cuda(x, "Conv2d 1x1")
+        dev = x.device
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        Cinp, Coutp = pad32(Cin), pad32(Cout)
+        x_t, px, _ = _raw(x, dtype)
+        wp = mod.cache.get(("cf", dtype), w, lambda: pack_conv(w, Cin, 0, dtype, 0, taps=1))
+
+        def biasp():
+            t = torch.zeros((Coutp,), dtype=torch.float32, device=dev)
+            t[:Cout] = _param_f32(b)
+            return t
+        bp = None if b is None else mod.cache.get(("cb", dtype), b, biasp)
+        out = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
+        _lib.call("segk_conv1x1", px, wp.data_ptr(), _p(bp), out.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype], _stream())
+        ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, Cin, Cout)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x_t, w)
+        return act_view(out, Cout)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x_t, w = ctx.saved_tensors
+        mod, dtype = ctx.mod, ctx.dtype
+        B, H, W, Cin, Cout = ctx.dims
+        dev = x_t.device
+        Cinp, Coutp = pad32(Cin), pad32(Cout)
+        d_t, pd, _ = _raw(dout, dtype)
+        px = act_info(x_t, dtype)[0]
+        dx = None
+        if ctx.needs_input_grad[1]:
+            wd = mod.cache.get(("cd", dtype), w, lambda: pack_conv(w, Cin, 0, dtype, 1, taps=1))
+            dxb = torch.empty((B, H, W, Cinp), dtype=dtype, device=dev)
+            _lib.call("segk_conv1x1", pd, wd.data_ptr(), 0, dxb.data_ptr(), B, H, W, Coutp, Cinp, _DT[dtype], _stream())
+            dx = act_view(dxb, Cin)
+        slabs, S = wgrad(pd, Coutp, px, Cinp, 0, 0, B, H, W, 1, dtype, dev)
+        dw = wgrad_to_param(slabs, S, w.shape, Cout, Cin, 0, 1, dev)
+        db = channel_sum(pd, B * H * W, Cout, dtype, dev) if ctx.has_bias else None
+        return None, dx, dw, db
+
+
+class HeadFn(torch.autograd.Function):
+    """Output nn.Conv2d(C, num_classes, 1) -- reference unet/unet.py:91,105; clip/clipunet.py:181,187.
+    Returns fp32 NCHW logits exactly like the reference module does."""
+
+    @staticmethod
+    def forward(ctx, mod, x, w, b):
+        dtype = mod.compute_dtype or _compute_dtype
+        _require_cuda(x, "output Conv2d")
+        dev = x.device
+        B, C, H, W = x.shape
+        ncls = w.shape[0]
+        if ncls > _lib.MAX_CLASSES:
+            raise RuntimeError(f"output head supports up to {_lib.MAX_CLASSES} classes, got {ncls}")
+        x_t, px, Cp = _raw(x, dtype)
+        w2 = _param_f32(w).reshape(ncls, C)
+        logits = torch.empty((B, ncls, H, W), dtype=torch.float32, device=dev)
+        _lib.call("segk_head_fwd", px, w2.data_ptr(), _param_f32(b).data_ptr(), logits.data_ptr(), B, H, W, Cp, C,
+                  ncls, _DT[dtype], _stream())
+        ctx.dtype, ctx.dims = dtype, (B, C, H, W, ncls)
+        ctx.save_for_backward(x_t, w)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x_t, w = ctx.saved_tensors
+        dtype = ctx.dtype
+        B, C, H, W, ncls = ctx.dims
+        dev = x_t.device
+        px, Cp = act_info(x_t, dtype)
+        dl = dlogits
+        if dl.dtype != torch.float32 or not dl.is_contiguous():
+            dl = dl.float().contiguous()
+        w2 = _param_f32(w).reshape(ncls, C)
+        dy = torch.empty((B, H, W, Cp), dtype=dtype, device=dev)
+        part = _f32(_lib.query("segk_head_part_floats", B * H * W, Cp), dev)
+        dw = torch.empty(w.shape, dtype=torch.float32, device=dev)
+        db = _f32(ncls, dev)
+        _lib.call("segk_head_bwd", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(), dw.data_ptr(),
+                  db.data_ptr(), B, H, W, Cp, C, ncls, _DT[dtype], _stream())
+        return None, act_view(dy, C), dw, db
+
+
+class SegLossFn(torch.autograd.Function):
+    """dice_weight * softDice + ce_weight * CrossEntropy in one pass over the logits --
+    reference utils/weighted_loss.py:31-98,140-166 and nn.CrossEntropyLoss as called at utils/training.py:47."""
+
+    @staticmethod
+    def forward(ctx, logits, target, class_weights, ignore_index, smooth, dice_weight, ce_weight):
+        _require_cuda(logits, "segmentation loss")
+        if logits.dim() != 4:
+            raise ValueError(f"expected logits [N,C,H,W], got {tuple(logits.shape)}")
+        N, C, H, W = logits.shape
+        if C > _lib.MAX_CLASSES:
+            raise RuntimeError(f"fused loss supports up to {_lib.MAX_CLASSES} classes, got {C}")
+        lg = logits.detach()
+        if lg.dtype != torch.float32 or not lg.is_contiguous():
+            lg = lg.float().contiguous()
+        tg = target.detach()
+        if tg.dtype != torch.int64 or not tg.is_contiguous():
+            tg = tg.long().contiguous()
+        if tg.numel() != N * H * W:
+            raise ValueError(f"target shape {tuple(target.shape)} does not match logits {tuple(logits.shape)}")
+        dev = logits.device
+        cw = None
+        if class_weights is not None:
+            cw = class_weights.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if cw.numel() != C:
+                raise ValueError("class_weights must have one entry per class")
+        ign = -1 if ignore_index is None else int(ignore_index)
+        part = _f32(_lib.query("segk_loss_part_floats", N * H * W), dev)
+        state = _f32(_lib.query("segk_loss_state_floats"), dev)
+        _lib.call("segk_loss_fwd", lg.data_ptr(), tg.data_ptr(), _p(cw), N, C, H * W, ign, float(smooth),
+                  float(dice_weight), float(ce_weight), part.data_ptr(), state.data_ptr(), _stream())
+        ctx.cfg = (N, C, H, W, ign, float(dice_weight), float(ce_weight))
+        ctx.save_for_backward(lg, tg, cw, state)
+        return state[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        lg, tg, cw, state = ctx.saved_tensors
+        N, C, H, W, ign, dw, cew = ctx.cfg
+        go = gout.detach().float().reshape(1).contiguous()
+        dl = torch.empty_like(lg)
+        _lib.call("segk_loss_bwd", lg.data_ptr(), tg.data_ptr(), _p(cw), state.data_ptr(), go.data_ptr(), N, C, H * W,
+                  ign, dw, cew, dl.data_ptr(), _stream())
+        return dl, None, None, None, None, None, None
+
+
+def confusion_matrix(logits, labels, num_classes):
+    """argmax over classes (first maximum, like torch.argmax) + confusion counts on device.
+    logits [N,C,H,W] or [C,H,W]; labels [N,H,W] / [H,W].  Returns int64 [num_classes, num_classes] with
+    M[pred, label] (reference utils/MetricsHistory.py:65-75 derives TP/FP/FN/TN from exactly these)."""
+    _require_cuda(logits, "confusion_matrix")
+    if logits.dim() == 3:
+        logits = logits.unsqueeze(0)
+    N, C, H, W = logits.shape
+    if C != num_classes or C > _lib.MAX_CLASSES:
+        raise ValueError(f"expected {num_classes} (<= {_lib.MAX_CLASSES}) class channels, got {C}")
+    lg = logits.detach()
+    if lg.dtype != torch.float32 or not lg.is_contiguous():
+        lg = lg.float().contiguous()
+    tg = labels.detach()
+    if tg.dtype != torch.int64 or not tg.is_contiguous():
+        tg = tg.long().contiguous()
+    if tg.numel() != N * H * W:
+        raise ValueError("label shape does not match logits")
+    M = torch.zeros((_lib.MAX_CLASSES, _lib.MAX_CLASSES), dtype=torch.int64, device=logits.device)
+    _lib.call("segk_confusion", lg.data_ptr(), tg.data_ptr(), N, C, H * W, M.data_ptr(), _stream())
+    return M[:C, :C]

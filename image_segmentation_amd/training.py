@@ -1,0 +1,230 @@
+"""Training / evaluation driver -- drop-in for the reference's utils/training.py (train_loop :18-64,
+eval_loop :67-121, start :453-618): same signatures, same accumulation/step/zero_grad order, same returned
+averages, same checkpoint dictionary keys.  Pure host logic: the model, loss and metrics it drives are the
+HIP-backed modules of this package (or anything honouring the same nn.Module protocol).
+
+Differences from the reference, all deliberate:
+  * progress bars use tqdm.auto when available (tqdm.notebook needs ipywidgets) and can be silenced;
+  * eval_loop prints per-class IoU for agg.get_num_classes() classes instead of a hard-coded 4
+    (training.py:81 raises IndexError with a 3-class aggregator);
+  * an optional `grad_sync` hook (parallel.GradSync) all-reduces gradients over RCCL right before
+    optimizer.step() -- absent in the single-process reference.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .metrics import MetricsHistory
+from .utils import process_batch_forward, process_batch_reverse, NEAREST
+
+try:                                    # plain tqdm; the reference's tqdm.notebook needs ipywidgets
+    from tqdm.auto import tqdm as _tqdm
+except Exception:                       # pragma: no cover
+    _tqdm = None
+
+VERBOSE = True
+
+
+def _bar(it, **kw):
+    if _tqdm is None or not VERBOSE:
+        return it
+    return _tqdm(it, **kw)
+
+
+def _say(*a):
+    if VERBOSE:
+        print(*a)
+
+
+def train_loop(dataloader, model, loss_fn, optimizer, accumulation_steps, device, scheduler=None, target_size=None,
+               grad_sync=None):
+    """One epoch (training.py:18-64).  Returns the mean, over optimizer steps, of the UNSCALED loss of the
+    last micro-batch of each accumulation window (training.py:58,62)."""
+    model.train()
+    total_loss = 0.0
+    processed_batches = 0
+
+    optimizer.zero_grad()
+
+    n = len(dataloader)
+    pbar = _bar(enumerate(dataloader), total=n, desc="Training")
+    for batch_idx, (X, y) in pbar:
+        if target_size is not None:
+            X, _ = process_batch_forward(X, target_size=target_size)
+            y, _ = process_batch_forward(y, target_size=target_size, interpolation=NEAREST)
+
+        X, y = X.to(device), y.to(device).long()
+        pred = model(X)
+        loss = loss_fn(pred, y.squeeze(1))
+
+        scaled_loss = loss / accumulation_steps
+        scaled_loss.backward()
+
+        if (batch_idx + 1) % accumulation_steps == 0 or (batch_idx + 1) == n:
+            if grad_sync is not None:
+                grad_sync.sync()
+            optimizer.step()
+            if scheduler:
+                scheduler.step()
+            optimizer.zero_grad()
+
+            total_loss += loss.item()
+            processed_batches += 1
+            if hasattr(pbar, "set_postfix"):
+                pbar.set_postfix({'loss': loss.item(), 'lr': optimizer.param_groups[0]['lr']})
+
+    avg_loss = total_loss / processed_batches if processed_batches > 0 else 0
+    _say(f"Training Avg loss (per effective batch): {avg_loss:>8f}")
+    return avg_loss
+
+
+def eval_loop(dataloader, model, loss_fn, device, target_size, agg):
+    """training.py:67-121: resize+pad -> model (eval mode, no_grad) -> reverse resize -> per-image loss at
+    the ORIGINAL size and confusion counts.  Returns (avg_loss, mean_dice, mean_iou)."""
+    model.eval()
+    num_images_processed = 0
+    total_loss = 0.0
+    num_classes = agg.get_num_classes()
+    agg.reset()
+
+    with torch.no_grad():
+        for X, y in _bar(dataloader, desc="Eval"):
+            X, meta_list = process_batch_forward(X, target_size=target_size)
+            X = X.to(device)
+            preds = model(X)
+
+            preds = process_batch_reverse(preds, meta_list, interpolation='bilinear')
+
+            for pred, label in zip(preds, y):
+                pred = pred.to(device)
+                label = label.to(device).long()
+
+                loss = loss_fn(pred.unsqueeze(0), label.unsqueeze(0).squeeze(1))
+                total_loss += loss.item()
+                agg.accumulate(pred, label)
+
+                num_images_processed += 1
+
+    avg_loss = total_loss / num_images_processed
+
+    mean_dice, mean_iou, mean_acc = agg.compute_epoch_metrics()
+    per_class_iou = agg.get_last_per_class_iou()
+    ignore_index = agg.get_ignore_index()
+
+    _say(f"\n--- Evaluation Complete ---")
+    _say(f"  Images Processed: {num_images_processed}")
+    _say(f"  Average Loss (Original Size): {avg_loss:>8f}")
+    _say(f"  Ignored Class : {ignore_index}")
+    _say(f"  Macro Avg Acc score: {mean_acc:>8f}")
+    _say(f"  Macro Avg Dice Score: {mean_dice:>8f}")
+    _say(f"  Mean IoU (mIoU): {mean_iou:>8f}")
+    _say(f"  --- Per-Class IoU ---")
+    for c in range(num_classes):
+        _say(f"    Class {c}: {per_class_iou[c].item():>8f}")
+    _say("-" * 25)
+
+    return avg_loss, mean_dice, mean_iou
+
+
+def start(
+        model_save_dir: str,
+        model_save_name: str,
+        model,
+        optimizer,
+        train_dataloader,
+        val_dataloader,
+        accumulation_steps: int,
+        device,
+        train_loss_fn,
+        val_loss_fn,
+        target_size: int,
+        scheduler=None,
+        agg: MetricsHistory = None,
+        load: bool = True,
+        save: bool = True,
+        num_classes: int = 4,
+        ignore_index: int = 3,
+        epochs: int = 100,
+        grad_sync=None,
+):
+    """training.py:453-618: optional resume, epoch loop, per-epoch metrics file, best-mIoU checkpoint
+    (+ weights-only "MO_<name>").  Checkpoint keys are the reference's."""
+    start_epoch = 0
+    best_dev_dice = -np.inf
+    best_dev_miou = -np.inf
+    best_dev_loss = np.inf
+
+    os.makedirs(model_save_dir, exist_ok=True)
+    os.makedirs(f"{model_save_dir}/metrics", exist_ok=True)
+    path = f"{model_save_dir}/{model_save_name}"
+    if load and os.path.isfile(path):
+        _say(f"Loading checkpoint from: {path}")
+        checkpoint = torch.load(path, map_location=device, weights_only=True)
+        model.load_state_dict(checkpoint["model_state_dict"])
+        _say(" -> Model state loaded.")
+        try:
+            optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+            _say(" -> Optimizer state loaded.")
+        except Exception as e:
+            _say(f" -> Warning: Could not load optimizer state: {e}. Optimizer will start from scratch.")
+        try:
+            scheduler.load_state_dict(checkpoint["scheduler_state_dict"])
+            _say(" -> Scheduler state loaded.")
+        except Exception as e:
+            _say(f" -> Warning: Could not load scheduler state: {e}. Scheduler will start from scratch.")
+        try:
+            agg = checkpoint.get("history")
+            agg.to(device)
+            _say(" -> Metrics History loaded.")
+        except Exception:
+            _say(" -> No metric history saved")
+            agg = MetricsHistory(num_classes, ignore_index)
+        start_epoch = checkpoint.get("epoch", 0)
+        best_dev_dice = checkpoint.get("best_dev_dice", -np.inf)
+        best_dev_miou = checkpoint.get("best_dev_miou", -np.inf)
+        best_dev_loss = checkpoint.get("best_dev_loss", np.inf)
+        _say(f" -> Resuming training from epoch {start_epoch + 1}")
+        _say(f" -> Loaded best metrics: Dice={best_dev_dice:.6f}, mIoU={best_dev_miou:.6f}, Loss={best_dev_loss:.6f}")
+        _say(f" -> Notes from checkpoint: {checkpoint.get('notes', 'N/A')}")
+    else:
+        _say(f"Checkpoint file not found at {path}. Starting training from scratch.")
+    if agg is None:
+        agg = MetricsHistory(num_classes, ignore_index)
+
+    _say("\nStarting Training...")
+    for t in range(start_epoch, epochs):
+        _say(f"Epoch {t+1}\n-------------------------------")
+        train_loop(train_dataloader, model, train_loss_fn, optimizer, accumulation_steps, device, scheduler,
+                   target_size, grad_sync=grad_sync)
+        val_loss, val_dice, val_miou = eval_loop(val_dataloader, model, val_loss_fn, device, target_size, agg)
+
+        if save:
+            torch.save({"epoch": t + 1, "history": agg}, f"{model_save_dir}/metrics/{model_save_name}")
+
+        if val_miou > best_dev_miou:
+            best_dev_dice, best_dev_miou, best_dev_loss = val_dice, val_miou, val_loss
+            if save:
+                _say(f"Validation IoU score improved ({best_dev_miou:.6f}). Saving model...")
+                checkpoint = {
+                    "epoch": t + 1,
+                    "model_state_dict": model.state_dict(),
+                    "optimizer_state_dict": optimizer.state_dict(),
+                    "best_dev_dice": best_dev_dice,
+                    "best_dev_miou": best_dev_miou,
+                    "best_dev_loss": best_dev_loss,
+                    "notes": f"Model saved based on best Micro Dice. Ignored index for metric: {ignore_index}",
+                }
+                if scheduler:
+                    checkpoint["scheduler_state_dict"] = scheduler.state_dict()
+                torch.save(checkpoint, path)
+                torch.save({"epoch": t + 1, "model_state_dict": model.state_dict()},
+                           f"{model_save_dir}/MO_{model_save_name}")
+        else:
+            _say(f"Validation IoU score did not improve from {best_dev_miou:.6f}")
+
+    _say("\n--- Training Finished! ---")
+    _say(f"Best validation IoU score achieved: {best_dev_miou:.6f}")
+    _say(f"Corresponding validation dice: {best_dev_dice:.6f}")
+    _say(f"Corresponding validation loss: {best_dev_loss:.6f}")
+    return best_dev_miou, best_dev_dice, best_dev_loss

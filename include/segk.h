@@ -1,0 +1,140 @@
+/* segk -- C ABI of the MI355X (gfx950) segmentation hot-path kernels.
+ *
+ * This is the drop-in boundary of the project: a shared library
+ * (image_segmentation_amd/csrc/libsegk.so) with plain-C entry points -- raw device pointers, ints and a
+ * HIP stream handle; no torch/C++ types cross it.  The reference (in5omnia/Image_Segmentation) has no
+ * FFI of its own: its hot path is a chain of stock torch.nn layers.  Each entry below names the
+ * reference layer(s) it replaces (file:line under the reference repo) so a maintainer can bind it from
+ * any host (ctypes stub in INTEGRATION.md; image_segmentation_amd/_lib.py is the binding we ship).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative code on failure; segk_last_error() returns a
+ *    thread-local message.  Nothing throws, allocates device memory, or synchronises the device:
+ *    all launches are asynchronous on `stream` (graph-capture safe); all buffers are caller-owned.
+ *  - activations are NHWC, channel count padded to a multiple of 32 ("Cp"); padded channels are zero.
+ *  - dtype: SEGK_F32 (exact fp32 MFMA, parity mode) or SEGK_BF16 (bf16 storage/MFMA, fp32 accumulate).
+ *  - parameters and their gradients stay in the reference layout and fp32 (OIHW conv weights, IOHW
+ *    transposed-conv weights, per-channel vectors); segk_pack_* convert them to the MFMA layout.
+ */
+#ifndef SEGK_H
+#define SEGK_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGK_F32 0
+#define SEGK_BF16 1
+#define SEGK_MAX_CLASSES 8
+
+typedef void* segk_stream_t; /* hipStream_t */
+
+int segk_version(void);
+const char* segk_last_error(void);
+
+/* ---- layout ------------------------------------------------------------------------------------ */
+/* NCHW fp32 [B,C,H,W] -> NHWC dtype [B,H,W,Cp] (zero padded).  Input edge of model(X), training.py:45-46 */
+int segk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cp, int dtype, segk_stream_t s);
+/* NHWC dtype [B,H,W,Cp] -> NCHW fp32 [B,C,H,W] */
+int segk_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cp, int dtype, segk_stream_t s);
+
+/* Conv2d weight OIHW fp32 [Cout][CA+CB][taps] -> MFMA layout [Kp/CH][taps][Np][CH] (CH = 16 fp32 / 32 bf16).
+ * The input channels may come from two NHWC sources (the skip concat of unet.py:63 / clipunet.py:102):
+ * CA/CB logical, CAp/CBp padded.  mode 0: forward weights; mode 1: data-gradient weights (flipped taps,
+ * in/out swapped).  taps = 9 (3x3) or 1 (1x1).  dst holds (CAp+CBp)*taps*Coutp elements. */
+int segk_pack_conv_weight(const float* w, void* dst, int Cout, int CA, int CB, int Coutp, int CAp, int CBp,
+                          int taps, int mode, int dtype, segk_stream_t s);
+/* ConvTranspose2d(k=2,s=2) weight IOHW fp32 [Cin][Cout][2][2] -> MFMA layout; mode 0 forward, 1 data-gradient */
+int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cinp, int Coutp, int mode, int dtype,
+                           segk_stream_t s);
+
+/* ---- Conv2d 3x3 pad 1 (unet/unet.py:16,19; clip/clipunet.py:87,90), forward and data-gradient -----
+ * out[B,H,W,CO1] (| out2[B,H,W,CO2]) = conv3x3( [srcA | srcB] , wpacked ) (+ bias).
+ * scale/shift != NULL: the producer layer's BatchNorm+ReLU is applied to srcA on load (fused prologue).
+ * stats != NULL: per-tile per-channel (sum, sumsq) partials [segk_conv_tiles()][CO1+CO2][2] for
+ * training-mode BatchNorm (finish with segk_bn_finalize).  For the data gradient pass mode-1 weights. */
+int segk_conv_tiles(int B, int H, int W);
+int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const float* bias, const float* scale,
+                 const float* shift, void* out, void* out2, float* stats, int B, int H, int W, int CA, int CB,
+                 int CO1, int CO2, int dtype, segk_stream_t s);
+/* Conv2d 1x1 (clip/clipunet.py:84,122): same contract, taps = 1 */
+int segk_conv1x1(const void* srcA, const void* wpacked, const float* bias, void* out, int B, int H, int W, int CA,
+                 int CO, int dtype, segk_stream_t s);
+/* ConvTranspose2d(k=2,s=2) forward (unet.py:59; clipunet.py:83): in [B,H,W,Cin] -> out [B,2H,2W,Cout];
+ * bias4 = the layer bias tiled over the four taps (length 4*Cout, zero in padded channels) or NULL */
+int segk_convt2x2_fwd(const void* in, const void* wpacked, const float* bias4, void* out, int B, int H, int W,
+                      int Cin, int Cout, int dtype, segk_stream_t s);
+/* ... its data gradient: dout [B,2H,2W,Cout] -> din [B,H,W,Cin]  (H,W are the INPUT grid) */
+int segk_convt2x2_dgrad(const void* dout, const void* wpacked, void* din, int B, int H, int W, int Cin, int Cout,
+                        int dtype, segk_stream_t s);
+
+/* ---- weight gradients ---------------------------------------------------------------------------
+ * slabs [S][CD][taps][CA+CB] fp32 = split-K partials of  sum_p dz[p][n] * a[p+tap][k]; then
+ * segk_wgrad_reduce sums them in fixed order into the reference-layout gradient (fp32, overwritten).
+ * geo 0: Conv2d 3x3 (grad OIHW [N][CA+CB][9]);  geo 1: Conv2d 1x1;  geo 2: ConvTranspose2d(k=2,s=2) with
+ * dz := layer input [B,H,W,CD], srcA := output gradient [B,2H,2W,CA], grad IOHW [CD][CA][2][2].
+ * scale/shift: BatchNorm+ReLU prologue on srcA (the conv input is relu(bn(z)) of the previous conv). */
+int segk_wgrad_tiles(int B, int H, int W, int geo, int dtype);
+int segk_wgrad(const void* dz, const void* srcA, const void* srcB, const float* scale, const float* shift,
+               float* slabs, int S, int B, int H, int W, int CD, int CA, int CB, int geo, int dtype, segk_stream_t s);
+int segk_wgrad_reduce(const float* slabs, int S, float* grad, int N, int CA, int CB, int Np, int CAp, int CBp,
+                      int taps, segk_stream_t s);
+
+/* ---- BatchNorm2d + ReLU (unet.py:17-18,20-21; clipunet.py:88-89,91-92) ---------------------------
+ * training: stats partials -> scale = gamma*rstd, shift = beta - mean*scale, batch mean/rstd saved for
+ * backward, running stats updated (momentum, unbiased var; conv_bias only shifts running_mean: the
+ * kernels work on the bias-free conv output because the bias cancels inside BatchNorm).
+ * eval: scale/shift from running statistics. */
+int segk_bn_finalize(const float* stats, int tiles, int Cp, int C, double count, const float* conv_bias,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, int training, float* scale, float* shift, float* mean, float* rstd, segk_stream_t s);
+/* y = relu(z*scale + shift) over P pixels */
+int segk_bn_relu_apply(const void* z, void* y, const float* scale, const float* shift, long P, int Cp, int dtype,
+                       segk_stream_t s);
+/* backward of y = relu(bn(z)): dz (may alias dy) and dgamma/dbeta.  part: segk_bn_bwd_blocks()*Cp*2 floats,
+ * coef: 2*Cp floats of scratch. */
+int segk_bn_bwd_blocks(long P, int Cp, int dtype);
+int segk_bn_relu_bwd(const void* dy, const void* z, void* dz, const float* scale, const float* shift,
+                     const float* mean, const float* rstd, long P, int Cp, int C, float* part, float* dgamma,
+                     float* dbeta, float* coef, int dtype, segk_stream_t s);
+
+/* per-channel sum over P pixels of an NHWC tensor: the bias gradient of ConvTranspose2d (unet.py:59) and of the
+ * 1x1 convs (clipunet.py:84,122).  part: segk_bn_bwd_blocks(P,Cp,dtype)*Cp floats of scratch. */
+int segk_channel_sum(const void* x, long P, int Cp, int C, float* part, float* out, int dtype, segk_stream_t s);
+
+/* ---- MaxPool2d(2,2) (unet.py:40) ---------------------------------------------------------------- */
+int segk_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int Cp, int dtype, segk_stream_t s);
+/* dx (+)= route(dy) to the first maximum of each window; accumulate=1 adds into dx (skip gradient) */
+int segk_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate,
+                        int dtype, segk_stream_t s);
+
+/* ---- output head: Conv2d(C, ncls, 1) (unet.py:91,105; clipunet.py:181,187) ----------------------- */
+/* y NHWC [B,H,W,Cp] -> logits NCHW fp32 [B,ncls,H,W];  w fp32 [ncls][C], bias [ncls] */
+int segk_head_fwd(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp,
+                  int C, int ncls, int dtype, segk_stream_t s);
+int segk_head_part_floats(long P, int Cp);
+int segk_head_bwd(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
+                  int B, int H, int W, int Cp, int C, int ncls, int dtype, segk_stream_t s);
+
+/* ---- per-pixel CrossEntropy + soft Dice (training.py:47; utils/weighted_loss.py:31-98,140-166) ----
+ * logits NCHW fp32 [N,C,HW], labels int64 [N,HW].  state (segk_loss_state_floats() floats):
+ * [0]=dice_weight*dice+ce_weight*ce, [1]=ce, [2]=dice, rest = saved statistics for backward.
+ * ignore_index < 0: none.  class_weights may be NULL. */
+int segk_loss_part_floats(long P);
+int segk_loss_state_floats(void);
+int segk_loss_fwd(const float* logits, const int64_t* labels, const float* class_weights, int N, int C, long HW,
+                  int ignore_index, float smooth, float dice_weight, float ce_weight, float* part, float* state,
+                  segk_stream_t s);
+int segk_loss_bwd(const float* logits, const int64_t* labels, const float* class_weights, const float* state,
+                  const float* grad_out, int N, int C, long HW, int ignore_index, float dice_weight, float ce_weight,
+                  float* dlogits, segk_stream_t s);
+
+/* ---- metric: argmax + confusion matrix (utils/MetricsHistory.py:65-75) ---------------------------
+ * M[pred*8 + label] += count (uint64, caller zeroes); TP/FP/FN/TN follow on the host. */
+int segk_confusion(const float* logits, const int64_t* labels, int N, int C, long HW, uint64_t* M, segk_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,244 @@
+"""GPU (-m gpu): each HIP kernel family through the C ABI against the CPU oracle (stock torch fp32 ops on
+the same seeded inputs).  fp32 mode must agree to ~1e-5 (exact-fp32 MFMA vs oneDNN summation order);
+bf16 mode is compared with a tolerance scaled to bf16 rounding of inputs/outputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.fill import fill, labels as fill_labels
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from image_segmentation_amd import ops as o
+    return o
+
+
+def tol(dtype, k):
+    """abs tolerance for a length-k dot product of O(1) operands"""
+    return 2e-5 * max(1.0, np.sqrt(k) / 8) if dtype == torch.float32 else 2.5e-2 * max(1.0, np.sqrt(k) / 8)
+
+
+def dev(t):
+    return t.cuda()
+
+
+def back(t):
+    return t.detach().float().cpu()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 32, 4, 4), (2, 70, 9, 3)])
+def test_layout_roundtrip(ops, dtype, shape):
+    x = fill(shape, 3, -1, 1)
+    a = ops.to_act(dev(x), dtype)
+    assert ops.act_info(a, dtype) is not None and a.shape == x.shape
+    ref = x.to(dtype).float()
+    assert torch.equal(back(a), ref)
+    assert torch.equal(ops.act_to_nchw(a).cpu(), ref)
+    # padding channels are zero
+    ptr, Cp = ops.act_info(a, dtype)
+    assert Cp % 32 == 0 and Cp >= shape[1]
+
+
+def _conv_direct(ops, x, w, dtype, xb=None, scale=None, shift=None, stats=False, mode=0):
+    """run segk_conv3x3 on act tensors; returns (out[, out2]) as NCHW fp32 cpu and stats"""
+    from image_segmentation_amd import _lib
+    B, CA, H, W = x.shape
+    CB = 0 if xb is None else xb.shape[1]
+    Cout = w.shape[0]
+    xa = ops.to_act(dev(x), dtype); pa, CAp = ops.act_info(xa, dtype)
+    pb, CBp = (0, 0)
+    if xb is not None:
+        xbt = ops.to_act(dev(xb), dtype); pb, CBp = ops.act_info(xbt, dtype)
+    wp = ops.pack_conv(dev(w), CA, CB, dtype, mode)
+    Coutp = ops.pad32(Cout)
+    out = torch.empty((B, H, W, Coutp), dtype=dtype, device="cuda")
+    tiles = _lib.query("segk_conv_tiles", B, H, W)
+    st = torch.zeros((tiles, Coutp, 2), dtype=torch.float32, device="cuda") if stats else None
+    ops.conv3x3(xa, pa, CAp, pb, CBp, wp, out.data_ptr(), Coutp, 0, 0, B, H, W, dtype,
+                scale=None if scale is None else dev(scale), shift=None if shift is None else dev(shift), stats=st)
+    torch.cuda.synchronize()
+    y = back(ops.act_view(out, Cout))
+    return (y, st.cpu()) if stats else y
+
+
+CONV_CASES = [  # B, Cin, Cout, H, W
+    (2, 32, 32, 16, 16), (1, 64, 64, 32, 32), (2, 3, 64, 24, 40), (1, 128, 128, 8, 8),
+    (3, 96, 160, 14, 14), (1, 32, 64, 17, 33), (2, 256, 64, 16, 48),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_forward(ops, dtype, case):
+    B, Cin, Cout, H, W = case
+    x = fill((B, Cin, H, W), 1, -1, 1)
+    w = fill((Cout, Cin, 3, 3), 2, -1, 1) / np.sqrt(9 * Cin)
+    xr, wr = x.to(dtype).float(), w.to(dtype).float()
+    ref = F.conv2d(xr, wr, padding=1)
+    y, st = _conv_direct(ops, x, w, dtype, stats=True)
+    assert (y - ref).abs().max().item() < tol(dtype, 1) * 1.5
+    # BN statistics partials: sum and sum of squares per channel (taken from the fp32 accumulators)
+    s = st.sum(0)[:Cout]
+    close = 1e-3 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=close, atol=close * B * H * W * 0.05)
+    assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=close, atol=close)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_prologue_and_dual(ops, dtype):
+    B, H, W = 2, 20, 36
+    # fused BN+ReLU prologue
+    z = fill((B, 64, H, W), 1, -2, 2); w = fill((32, 64, 3, 3), 2, -1, 1) / 24
+    sc = fill((64,), 3, -1.5, 1.5); sh = fill((64,), 4, -0.5, 0.5)
+    zr = z.to(dtype).float()
+    a = torch.relu(zr * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dtype).float()
+    ref = F.conv2d(a, w.to(dtype).float(), padding=1)
+    y = _conv_direct(ops, z, w, dtype, scale=sc, shift=sh)
+    assert (y - ref).abs().max().item() < tol(dtype, 1) * 2
+    # two sources == conv of the concatenation (40 + 72 channels: both padded, 40 -> 64, 72 -> 96)
+    xa = fill((B, 40, H, W), 5, -1, 1); xb = fill((B, 72, H, W), 6, -1, 1)
+    w2 = fill((64, 112, 3, 3), 7, -1, 1) / 32
+    ref = F.conv2d(torch.cat([xa, xb], 1).to(dtype).float(), w2.to(dtype).float(), padding=1)
+    y = _conv_direct(ops, xa, w2, dtype, xb=xb)
+    assert (y - ref).abs().max().item() < tol(dtype, 1) * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_dgrad_weights(ops, dtype):
+    """mode-1 packing turns the same kernel into the data gradient"""
+    B, Cin, Cout, H, W = 2, 64, 96, 12, 20
+    w = fill((Cout, Cin, 3, 3), 2, -1, 1) / np.sqrt(9 * Cout)
+    g = fill((B, Cout, H, W), 3, -1, 1)
+    ref = F.conv_transpose2d(g.to(dtype).float(), w.to(dtype).float(), padding=1)
+    from image_segmentation_amd import _lib
+    ga = ops.to_act(dev(g), dtype); pg, Gp = ops.act_info(ga, dtype)
+    wd = ops.pack_conv(dev(w), Cin, 0, dtype, 1)
+    out = torch.empty((B, H, W, ops.pad32(Cin)), dtype=dtype, device="cuda")
+    ops.conv3x3(ga, pg, Gp, 0, 0, wd, out.data_ptr(), ops.pad32(Cin), 0, 0, B, H, W, dtype)
+    assert (back(ops.act_view(out, Cin)) - ref).abs().max().item() < tol(dtype, 1) * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 32, 32, 16, 16, 0), (1, 64, 128, 24, 40, 0), (2, 3, 64, 20, 20, 0),
+                                  (3, 96, 64, 14, 14, 0), (2, 40, 32, 9, 21, 72)])
+def test_wgrad_conv3x3(ops, dtype, case):
+    B, Cin, Cout, H, W, CB = case
+    x = fill((B, Cin, H, W), 1, -1, 1); g = fill((B, Cout, H, W), 2, -1, 1)
+    xb = fill((B, CB, H, W), 3, -1, 1) if CB else None
+    xin = x if xb is None else torch.cat([x, xb], 1)
+    xr = xin.to(dtype).float().requires_grad_(False)
+    w = torch.zeros((Cout, Cin + CB, 3, 3), requires_grad=True)
+    F.conv2d(xr, w, padding=1).backward(g.to(dtype).float())
+    ga = ops.to_act(dev(g), dtype); pg, Gp = ops.act_info(ga, dtype)
+    xa = ops.to_act(dev(x), dtype); pa, Ap = ops.act_info(xa, dtype)
+    pb, Bp = 0, 0
+    if xb is not None:
+        xbt = ops.to_act(dev(xb), dtype); pb, Bp = ops.act_info(xbt, dtype)
+    slabs, S = ops.wgrad(pg, Gp, pa, Ap, pb, Bp, B, H, W, 0, dtype, "cuda")
+    dw = ops.wgrad_to_param(slabs, S, w.shape, Cout, Cin, CB, 9, "cuda").cpu()
+    scale = np.sqrt(B * H * W)
+    assert (dw - w.grad).abs().max().item() < tol(dtype, 1) * scale * 0.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_prologue(ops, dtype):
+    B, C, H, W = 2, 64, 16, 24
+    z = fill((B, C, H, W), 1, -2, 2); g = fill((B, 32, H, W), 2, -1, 1)
+    sc = fill((C,), 3, -1.5, 1.5); sh = fill((C,), 4, -0.5, 0.5)
+    a = torch.relu(z.to(dtype).float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dtype).float()
+    w = torch.zeros((32, C, 3, 3), requires_grad=True)
+    F.conv2d(a, w, padding=1).backward(g.to(dtype).float())
+    ga = ops.to_act(dev(g), dtype); pg, Gp = ops.act_info(ga, dtype)
+    za = ops.to_act(dev(z), dtype); pz, Zp = ops.act_info(za, dtype)
+    slabs, S = ops.wgrad(pg, Gp, pz, Zp, 0, 0, B, H, W, 0, dtype, "cuda", scale=dev(sc), shift=dev(sh))
+    dw = ops.wgrad_to_param(slabs, S, w.shape, 32, C, 0, 9, "cuda").cpu()
+    assert (dw - w.grad).abs().max().item() < tol(dtype, 1) * np.sqrt(B * H * W) * 0.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_relu_bwd(ops, dtype):
+    B, C, H, W = 3, 40, 10, 14
+    z0 = fill((B, C, H, W), 1, -2, 2).to(dtype).float()
+    g0 = fill((B, C, H, W), 2, -1, 1).to(dtype).float()
+    gamma = fill((C,), 3, 0.5, 1.5); beta = fill((C,), 4, -0.3, 0.3)
+    z = z0.clone().requires_grad_(True)
+    gam = gamma.clone().requires_grad_(True); bet = beta.clone().requires_grad_(True)
+    y = torch.relu(F.batch_norm(z, None, None, gam, bet, True, 0.1, 1e-5))
+    y.backward(g0)
+    mean = z0.mean(dim=(0, 2, 3)); var = z0.var(dim=(0, 2, 3), unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    Cp = ops.pad32(C)
+    pad = lambda v: dev(torch.cat([v, torch.zeros(Cp - C)]))
+    scale = pad(gamma * rstd); shift = pad(beta - mean * gamma * rstd)
+    za = ops.to_act(dev(z0), dtype); ga = ops.to_act(dev(g0), dtype)
+    out = torch.empty((B, H, W, Cp), dtype=dtype, device="cuda")
+    dg, db = ops.bn_relu_bwd(ops.act_info(ga, dtype)[0], ops.act_info(za, dtype)[0], out.data_ptr(), scale, shift,
+                             pad(mean), pad(rstd), B * H * W, C, dtype, "cuda")
+    t = 1e-4 if dtype == torch.float32 else 3e-2
+    assert torch.allclose(dg.cpu(), gam.grad, rtol=t, atol=t * 5)
+    assert torch.allclose(db.cpu(), bet.grad, rtol=t, atol=t * 5)
+    assert (back(ops.act_view(out, C)) - z.grad).abs().max().item() < t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 32, 8, 8), (1, 70, 6, 10), (2, 64, 7, 9)])
+def test_maxpool(ops, dtype, shape):
+    x0 = fill(shape, 1, -1, 1).to(dtype).float()
+    x0[0, :, 0, 0] = x0[0, :, 0, 1]            # a tie: gradient must go to the FIRST maximum
+    x = x0.clone().requires_grad_(True)
+    y = F.max_pool2d(x, 2, 2)
+    g0 = fill(tuple(y.shape), 2, -1, 1).to(dtype).float()
+    y.backward(g0)
+    xa = ops.to_act(dev(x0), dtype).requires_grad_(True)
+    ya = ops.MaxPoolFn.apply(xa, dtype)
+    assert torch.equal(back(ya), y.detach())
+    ya.backward(ops.to_act(dev(g0), dtype))
+    assert torch.equal(back(xa.grad), x.grad)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_loss_kernels(ops, dtype, golden):
+    if dtype != torch.float32:
+        pytest.skip("loss kernels are fp32 only")
+    from image_segmentation_amd import losses
+    g = golden("losses_small")
+    lg0 = fill((2, 4, 12, 20), 41, -3, 3); Y = fill_labels((2, 12, 20), 42, 4)
+    w4 = torch.tensor([0.3, 1.1, 0.9, 1.7])
+    cases = {
+        "ce": (losses.CrossEntropyLoss(), Y),
+        "ce_w": (losses.CrossEntropyLoss(weight=w4), Y),
+        "ce_w_ign3": (losses.CrossEntropyLoss(weight=w4, ignore_index=3), Y),
+        "dice": (losses.WeightedMemoryEfficientDiceLoss(smooth=1e-5), Y.unsqueeze(1)),
+        "dice_w_ign3": (losses.WeightedMemoryEfficientDiceLoss(smooth=1.0, class_weights=w4, ignore_index=3), Y.unsqueeze(1)),
+        "dicece": (losses.WeightedDiceCELoss(), Y),
+        "dicece_w_ign3": (losses.WeightedDiceCELoss(dice_weight=0.7, ce_weight=1.3, ignore_index=3, class_weights=w4,
+                                                    smooth_dice=1.0), Y.unsqueeze(1)),
+    }
+    for k, (fn, y) in cases.items():
+        l = dev(lg0).requires_grad_(True)
+        v = fn(l, dev(y)); v.backward()
+        assert abs(v.item() - float(g[k])) < 5e-6, k
+        np.testing.assert_allclose(l.grad.cpu().numpy(), g[k + "_grad"], rtol=2e-4, atol=2e-8, err_msg=k)
+    with pytest.raises(ValueError):
+        losses.WeightedMemoryEfficientDiceLoss()(dev(lg0), dev(Y))
+
+
+def test_confusion(ops):
+    lg = fill((3, 4, 9, 11), 5, -1, 1); lg[0, 1, 0, 0] = lg[0, 2, 0, 0] = 5.0   # tie -> lowest index
+    Y = fill_labels((3, 9, 11), 6, 4)
+    M = ops.confusion_matrix(dev(lg), dev(Y), 4).cpu()
+    hard = lg.argmax(1)
+    ref = torch.zeros(4, 4, dtype=torch.int64)
+    for p in range(4):
+        for l in range(4):
+            ref[p, l] = ((hard == p) & (Y == l)).sum()
+    assert torch.equal(M, ref)
