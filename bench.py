@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the U-Net 3-class training step (forward + CrossEntropy + backward +
+RCCL gradient all-reduce + AdamW) on synthetic 3x256x256 batches, B=32 per GPU (BASELINE.json config 2 at
+N=1, config 3 at N=8; weak scaling), on the hand-written HIP kernels in bf16 (fp32 accumulation / statistics /
+master parameters).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
+  roofline     : the dominant kernel family of the step, timed live with HIP events on the launch stream in
+                 a separate instrumented pass (the timed region itself carries no instrumentation);
+  cpu_baseline : the CPU oracle (oracle/, stock PyTorch fp32 ops = the reference algorithm) timed on the host
+                 cores on a bounded sample of the same workload (rank 0, N=1 only);
+  kernels      : per-kernel-family ms/step and achieved TFLOP/s / GB/s (algorithmic counts).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md); 6.29e12 measured copy ceiling
+HBM_COPY = 6.29e12
+MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}
+# algorithmic DoubleConv bytes per image (fwd+bwd, phase model), 2 B/elem at 256x256
+DC_BYTES_PER_IMAGE_BF16_256 = 593.7e6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--loss", choices=["ce", "dicece"], default="ce")
+    ap.add_argument("--profile-steps", type=int, default=3, help="instrumented steps for the roofline block")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import image_segmentation_amd as seg
+    from image_segmentation_amd import ops
+    from image_segmentation_amd.parallel import GradSync
+    from oracle.fill import fill, labels          # deterministic synthetic data (portable fill)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    seg.set_compute_dtype(dtype)
+    B, S = args.batch, args.size
+    torch.manual_seed(1234)                       # identical random-init weights on every rank
+    model = seg.unet(3, 3).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), weight_decay=0.01, fused=True)
+    if args.loss == "ce":
+        loss_fn = seg.CrossEntropyLoss()
+    else:
+        cw = torch.tensor([0.2046795970925636, 1.0271954434416883, 1.2293222812780409])
+        loss_fn = seg.WeightedDiceCELoss(smooth_dice=1.0, class_weights=cw)
+    X = fill((B, 3, S, S), 1 + 2 * rank, 0, 1).to(dev)           # images resident in HBM before timing
+    Y = labels((B, S, S), 2 + 2 * rank, 3).to(dev)
+    gs = GradSync(model) if world > 1 else None
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        if gs is not None:
+            gs.arm()
+        loss = loss_fn(model(X), Y)
+        loss.backward()
+        if gs is not None:
+            gs.sync()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    # ---- instrumented pass (rank 0): per-kernel-family HIP-event timings on the launch stream
+    prof = {}
+    if rank == 0 and args.profile_steps > 0:
+        ops.TIMER = ops.KernelTimer()
+        for _ in range(args.profile_steps):
+            step()
+        prof = ops.TIMER.summary()
+        ops.TIMER = None
+    if world > 1:
+        dist.barrier()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n = max(1, args.profile_steps)
+    peak = MFMA_PEAK[args.dtype]
+    kernels = {}
+    for tag, r in prof.items():
+        ms = r["ms"] / n
+        kernels[tag] = {
+            "launches_per_step": r["launches"] // n, "ms_per_step": round(ms, 4),
+            "tflops": round(r["flops"] / n / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+            "alg_GBps": round(r["bytes"] / n / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+        }
+    roofline = None
+    if prof:
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        r = prof[dom]
+        launches = max(1, r["launches"])
+        avg_s = r["ms"] * 1e-3 / launches
+        fl, by = r["flops"] / launches, r["bytes"] / launches
+        mfma_bound = (fl / peak) >= (by / HBM_PEAK)
+        if mfma_bound:
+            ach = fl / avg_s / 1e12
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                        "frac": round(ach / (peak / 1e12), 4)}
+        else:
+            ach = by / avg_s / 1e9
+            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": round(ach / (HBM_PEAK / 1e9), 4)}
+        roofline.update({"kernel": dom, "launches_per_step": r["launches"] // n,
+                         "avg_launch_us": round(avg_s * 1e6, 2),
+                         "alg_flops_per_launch": fl, "alg_bytes_per_launch": by,
+                         "hbm_frac_same_kernel": round(by / avg_s / HBM_PEAK, 4), "traffic": None})
+
+    img_s = world * B * args.steps / dt
+    # DoubleConv-scope HBM roofline of SURVEY 8(d): kernels of the 9 DoubleConv blocks only
+    dc_tags = ("conv3x3_igemm", "wgrad3x3", "wgrad_reduce", "bn_relu_bwd", "bn_relu_apply")
+    dc_ms = sum(kernels[t]["ms_per_step"] for t in dc_tags if t in kernels)
+    scope = None
+    if dc_ms > 0 and args.dtype == "bf16":
+        per_img = DC_BYTES_PER_IMAGE_BF16_256 * (S * S) / (256 * 256)
+        gbps = per_img * B / (dc_ms * 1e-3) / 1e9
+        scope = {"doubleconv_ms_per_step": round(dc_ms, 3), "alg_bytes_per_image": per_img,
+                 "alg_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps * 1e9 / HBM_PEAK, 4),
+                 "frac_of_6.29TBps_copy": round(gbps * 1e9 / HBM_COPY, 4)}
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(S)
+
+    out = {
+        "metric": "images/sec (fwd+bwd) U-Net 3-class 256x256; IoU parity vs CPU ref",
+        "value": round(img_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"unet(3,3) train step (fwd + {args.loss} + bwd + grad all-reduce + AdamW), "
+                               f"B={B}/GPU 3x{S}x{S}, BASELINE config {2 if world == 1 else 3}",
+                   "global_batch": B * world, "image": [3, S, S], "parallelism": f"dp{world}",
+                   "final_loss": round(final_loss, 5)},
+        "roofline": roofline, "cpu_baseline": cpu, "doubleconv_scope": scope, "kernels": kernels,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(S):
+    """The CPU oracle (= the reference algorithm in stock PyTorch fp32 ops) on a bounded sample of the same
+    workload: 4 of the 32 images per step, 1 warm-up + 2 timed train steps on the host cores."""
+    import torch
+    from oracle import unet_ref, losses_ref
+    from oracle.fill import fill, labels, fill_module
+    threads = torch.get_num_threads()
+    Bc = 4
+    m = unet_ref.unet(3, 3); fill_module(m, 1000); m.train()
+    opt = torch.optim.AdamW(m.parameters(), weight_decay=0.01)
+    X = fill((Bc, 3, S, S), 1, 0, 1); Y = labels((Bc, S, S), 2, 3)
+
+    def step():
+        opt.zero_grad()
+        loss = losses_ref.cross_entropy(m(X), Y)
+        loss.backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    k = 2
+    for _ in range(k):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc * k / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle unet(3,3) fp32 train step (fwd+CE+bwd+AdamW), B={Bc} of 32 images 3x{S}x{S}, "
+                      f"1 warm-up + {k} timed steps, torch CPU {threads} threads"}
+
+
+if __name__ == "__main__":
+    main()

@@ -151,35 +151,103 @@ def pack_convt(w, dtype, mode):
 
 
 # ------------------------------------------------------------------------------------------------
+# optional per-kernel-family timing (bench.py): HIP events recorded on the launch stream around each call
+class KernelTimer:
+    """Collects (start, end) HIP-event pairs plus algorithmic flops/bytes per kernel family.  Events are
+    recorded on torch's current stream, which is the stream every segk launch uses."""
+
+    def __init__(self):
+        self.rows = {}
+
+    def span(self, tag, flops=0.0, nbytes=0.0):
+        return _Span(self, tag, flops, nbytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, r in self.rows.items():
+            ms = sum(a.elapsed_time(b) for a, b in r["ev"])
+            out[tag] = {"launches": len(r["ev"]), "ms": ms, "flops": r["flops"], "bytes": r["bytes"]}
+        return out
+
+
+class _Span:
+    def __init__(self, timer, tag, flops, nbytes):
+        self.t, self.tag, self.flops, self.nbytes = timer, tag, flops, nbytes
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
+        r = self.t.rows.setdefault(self.tag, {"ev": [], "flops": 0.0, "bytes": 0.0})
+        r["ev"].append((self.a, b))
+        r["flops"] += self.flops
+        r["bytes"] += self.nbytes
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOSPAN = _NoSpan()
+TIMER = None          # set to a KernelTimer() to collect per-kernel timings
+
+
+def _span(tag, flops=0.0, nbytes=0.0):
+    return _NOSPAN if TIMER is None else TIMER.span(tag, flops, nbytes)
+
+
+def _es(dtype):
+    return 2 if dtype == torch.bfloat16 else 4
+
+
+# ------------------------------------------------------------------------------------------------
 # thin wrappers over the C ABI (all asynchronous on the current stream)
 def _f32(n, dev):
     return torch.empty((n,), dtype=torch.float32, device=dev)
 
 
 def conv3x3(srcA, ptrA, CAp, ptrB, CBp, wpacked, out_ptr, CO1p, out2_ptr, CO2p, B, H, W, dtype, scale=None,
-            shift=None, stats=None):
-    _lib.call("segk_conv3x3", ptrA, ptrB, wpacked.data_ptr(), 0, _p(scale), _p(shift), out_ptr, out2_ptr, _p(stats),
-              B, H, W, CAp, CBp, CO1p, CO2p, _DT[dtype], _stream())
+            shift=None, stats=None, alg=None, tag="conv3x3_igemm"):
+    """alg = (logical Cin, logical Cout) for the algorithmic flop/byte count (defaults to the padded sizes)."""
+    cin, cout = alg if alg else (CAp + CBp, CO1p + CO2p)
+    P, e = B * H * W, _es(dtype)
+    with _span(tag, 2.0 * P * 9 * cin * cout, P * (cin + cout) * e + 9.0 * cin * cout * e):
+        _lib.call("segk_conv3x3", ptrA, ptrB, wpacked.data_ptr(), 0, _p(scale), _p(shift), out_ptr, out2_ptr,
+                  _p(stats), B, H, W, CAp, CBp, CO1p, CO2p, _DT[dtype], _stream())
 
 
-def wgrad(dz_ptr, CDp, ptrA, CAp, ptrB, CBp, B, H, W, geo, dtype, dev, scale=None, shift=None):
+def wgrad(dz_ptr, CDp, ptrA, CAp, ptrB, CBp, B, H, W, geo, dtype, dev, scale=None, shift=None, alg=None):
     """Returns the slabs tensor and S (split-K factor)."""
     taps = {0: 9, 1: 1, 2: 4}[geo]
+    cd, ck = alg if alg else (CDp, CAp + CBp)
+    P, e = B * H * W, _es(dtype)
+    pk = P * (4 if geo == 2 else 1)
     tiles = _lib.query("segk_wgrad_tiles", B, H, W, geo, _DT[dtype])
     wc = 2 if CDp % 64 == 0 else 1
     wi = 2 if (CAp % 64 == 0 and CBp % 64 == 0) else 1
     nct = (CDp // (32 * wc)) * ((CAp + CBp) // (32 * wi))
     S = max(1, min(tiles, 1024 // nct if nct < 1024 else 1))
     slabs = _f32(S * CDp * taps * (CAp + CBp), dev)
-    _lib.call("segk_wgrad", dz_ptr, ptrA, ptrB, _p(scale), _p(shift), slabs.data_ptr(), S, B, H, W, CDp, CAp, CBp,
-              geo, _DT[dtype], _stream())
+    tag = {0: "wgrad3x3", 1: "wgrad1x1", 2: "wgrad_convt"}[geo]
+    with _span(tag, 2.0 * P * taps * cd * ck, (P * cd + pk * ck) * e + 4.0 * taps * cd * ck):
+        _lib.call("segk_wgrad", dz_ptr, ptrA, ptrB, _p(scale), _p(shift), slabs.data_ptr(), S, B, H, W, CDp, CAp, CBp,
+                  geo, _DT[dtype], _stream())
     return slabs, S
 
 
 def wgrad_to_param(slabs, S, shape, N, CA, CB, taps, dev):
     grad = torch.empty(shape, dtype=torch.float32, device=dev)
-    _lib.call("segk_wgrad_reduce", slabs.data_ptr(), S, grad.data_ptr(), N, CA, CB, pad32(N), pad32(CA),
-              pad32(CB) if CB else 0, taps, _stream())
+    with _span("wgrad_reduce", 0.0, 4.0 * (S + 1) * grad.numel()):
+        _lib.call("segk_wgrad_reduce", slabs.data_ptr(), S, grad.data_ptr(), N, CA, CB, pad32(N), pad32(CA),
+                  pad32(CB) if CB else 0, taps, _stream())
     return grad
 
 
@@ -198,9 +266,10 @@ def bn_relu_bwd(dy_ptr, z_ptr, dz_ptr, scale, shift, mean, rstd, P, C, dtype, de
     nb = _lib.query("segk_bn_bwd_blocks", P, Cp, _DT[dtype])
     part, coef = _f32(nb * Cp * 2, dev), _f32(2 * Cp, dev)
     dgamma, dbeta = _f32(C, dev), _f32(C, dev)
-    _lib.call("segk_bn_relu_bwd", dy_ptr, z_ptr, dz_ptr, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-              rstd.data_ptr(), P, Cp, C, part.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(),
-              _DT[dtype], _stream())
+    with _span("bn_relu_bwd", 0.0, 5.0 * P * C * _es(dtype)):     # reduce: 2 reads; apply: 2 reads + 1 write
+        _lib.call("segk_bn_relu_bwd", dy_ptr, z_ptr, dz_ptr, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), P, Cp, C, part.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(),
+                  _DT[dtype], _stream())
     return dgamma, dbeta
 
 
@@ -251,7 +320,7 @@ class DoubleConvFn(torch.autograd.Function):
 
         z1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         st1 = _f32(tiles * Coutp * 2, dev) if training else None
-        conv3x3(xa_t, pA, CAp, pB, CBp, w1p, z1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, stats=st1)
+        conv3x3(xa_t, pA, CAp, pB, CBp, w1p, z1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, stats=st1, alg=(CA + CB, Cout))
         mom1 = bn1.momentum if bn1.momentum is not None else 0.1
         sc1, sh1, mu1, rs1 = bn_finalize(st1, tiles, Cout, P, None if b1 is None else _param_f32(b1), _param_f32(g1),
                                          _param_f32(be1), bn1.running_mean, bn1.running_var, mom1, bn1.eps, training,
@@ -259,7 +328,7 @@ class DoubleConvFn(torch.autograd.Function):
         z2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         st2 = _f32(tiles * Coutp * 2, dev) if training else None
         conv3x3(z1, z1.data_ptr(), Coutp, 0, 0, w2p, z2.data_ptr(), Coutp, 0, 0, B, H, W, dtype, scale=sc1, shift=sh1,
-                stats=st2)
+                stats=st2, alg=(Cout, Cout))
         mom2 = bn2.momentum if bn2.momentum is not None else 0.1
         sc2, sh2, mu2, rs2 = bn_finalize(st2, tiles, Cout, P, None if b2 is None else _param_f32(b2), _param_f32(g2),
                                          _param_f32(be2), bn2.running_mean, bn2.running_var, mom2, bn2.eps, training,
@@ -268,8 +337,9 @@ class DoubleConvFn(torch.autograd.Function):
             bn1.num_batches_tracked.add_(1)
             bn2.num_batches_tracked.add_(1)
         y = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        _lib.call("segk_bn_relu_apply", z2.data_ptr(), y.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), P, Coutp,
-                  _DT[dtype], _stream())
+        with _span("bn_relu_apply", 0.0, 2.0 * P * Cout * _es(dtype)):
+            _lib.call("segk_bn_relu_apply", z2.data_ptr(), y.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), P, Coutp,
+                      _DT[dtype], _stream())
 
         ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, CA, CB, Cout)
         ctx.training = training
@@ -296,8 +366,9 @@ class DoubleConvFn(torch.autograd.Function):
         dg2, dbe2 = bn_relu_bwd(pdy, z2.data_ptr(), dz2.data_ptr(), sc2, sh2, mu2, rs2, P, Cout, dtype, dev)
         w2d = mod.cache.get(("w2d", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 1))
         da1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        conv3x3(dz2, dz2.data_ptr(), Coutp, 0, 0, w2d, da1.data_ptr(), Coutp, 0, 0, B, H, W, dtype)
-        slabs, S = wgrad(dz2.data_ptr(), Coutp, z1.data_ptr(), Coutp, 0, 0, B, H, W, 0, dtype, dev, scale=sc1, shift=sh1)
+        conv3x3(dz2, dz2.data_ptr(), Coutp, 0, 0, w2d, da1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, alg=(Cout, Cout))
+        slabs, S = wgrad(dz2.data_ptr(), Coutp, z1.data_ptr(), Coutp, 0, 0, B, H, W, 0, dtype, dev, scale=sc1, shift=sh1,
+                         alg=(Cout, Cout))
         dw2 = wgrad_to_param(slabs, S, w2.shape, Cout, Cout, 0, 9, dev)
         del slabs, dz2
 
@@ -309,10 +380,11 @@ class DoubleConvFn(torch.autograd.Function):
             w1d = mod.cache.get(("w1d", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 1))
             dxa_buf = torch.empty((B, H, W, CAp), dtype=dtype, device=dev)
             dxb_buf = torch.empty((B, H, W, CBp), dtype=dtype, device=dev) if CB else None
-            conv3x3(dz1, dz1.data_ptr(), Coutp, 0, 0, w1d, dxa_buf.data_ptr(), CAp, _p(dxb_buf), CBp, B, H, W, dtype)
+            conv3x3(dz1, dz1.data_ptr(), Coutp, 0, 0, w1d, dxa_buf.data_ptr(), CAp, _p(dxb_buf), CBp, B, H, W, dtype,
+                    alg=(Cout, CA + CB))
             dxa = act_view(dxa_buf, CA)
             dxb = act_view(dxb_buf, CB) if CB else None
-        slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev)
+        slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev, alg=(Cout, CA + CB))
         dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev)
         # conv biases ahead of a batch-statistics BatchNorm have an identically zero gradient
         db1 = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_bias[0] else None
@@ -329,7 +401,8 @@ class MaxPoolFn(torch.autograd.Function):
         x_t, px, Cp = _raw(x, dtype)
         B, C, H, W = x.shape
         y = torch.empty((B, H // 2, W // 2, Cp), dtype=dtype, device=x.device)
-        _lib.call("segk_maxpool2x2_fwd", px, y.data_ptr(), B, H, W, Cp, _DT[dtype], _stream())
+        with _span("maxpool_fwd", 0.0, 1.25 * B * H * W * C * _es(dtype)):
+            _lib.call("segk_maxpool2x2_fwd", px, y.data_ptr(), B, H, W, Cp, _DT[dtype], _stream())
         ctx.save_for_backward(x_t)
         ctx.dtype = dtype
         return act_view(y, C)
@@ -342,7 +415,8 @@ class MaxPoolFn(torch.autograd.Function):
         px, Cp = act_info(x_t, dtype)
         dy_t, pdy, _ = _raw(dy, dtype)
         dx = torch.empty((B, H, W, Cp), dtype=dtype, device=x_t.device)
-        _lib.call("segk_maxpool2x2_bwd", px, pdy, dx.data_ptr(), B, H, W, Cp, 0, _DT[dtype], _stream())
+        with _span("maxpool_bwd", 0.0, 2.25 * B * H * W * C * _es(dtype)):
+            _lib.call("segk_maxpool2x2_bwd", px, pdy, dx.data_ptr(), B, H, W, Cp, 0, _DT[dtype], _stream())
         return act_view(dx, C), None
 
 
@@ -367,8 +441,9 @@ class ConvT2x2Fn(torch.autograd.Function):
             return t
         b4 = None if b is None else mod.cache.get(("tb", dtype), b, bias4)
         out = torch.empty((B, 2 * H, 2 * W, Coutp), dtype=dtype, device=dev)
-        _lib.call("segk_convt2x2_fwd", px, wp.data_ptr(), _p(b4), out.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
-                  _stream())
+        with _span("convt_fwd", 2.0 * B * H * W * Cin * 4 * Cout, B * H * W * (Cin + 4 * Cout) * _es(dtype)):
+            _lib.call("segk_convt2x2_fwd", px, wp.data_ptr(), _p(b4), out.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
+                      _stream())
         ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, Cin, Cout)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x_t, w)
@@ -387,10 +462,11 @@ class ConvT2x2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             wd = mod.cache.get(("td", dtype), w, lambda: pack_convt(w, dtype, 1))
             dxb = torch.empty((B, H, W, Cinp), dtype=dtype, device=dev)
-            _lib.call("segk_convt2x2_dgrad", pd, wd.data_ptr(), dxb.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
-                      _stream())
+            with _span("convt_dgrad", 2.0 * B * H * W * Cin * 4 * Cout, B * H * W * (Cin + 4 * Cout) * _es(dtype)):
+                _lib.call("segk_convt2x2_dgrad", pd, wd.data_ptr(), dxb.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
+                          _stream())
             dx = act_view(dxb, Cin)
-        slabs, S = wgrad(px, Cinp, pd, Coutp, 0, 0, B, H, W, 2, dtype, dev)
+        slabs, S = wgrad(px, Cinp, pd, Coutp, 0, 0, B, H, W, 2, dtype, dev, alg=(Cin, Cout))
         dw = wgrad_to_param(slabs, S, w.shape, Cin, Cout, 0, 4, dev)
         db = channel_sum(pd, B * 4 * H * W, Cout, dtype, dev) if ctx.has_bias else None
         return None, dx, dw, db
@@ -459,8 +535,9 @@ class HeadFn(torch.autograd.Function):
         x_t, px, Cp = _raw(x, dtype)
         w2 = _param_f32(w).reshape(ncls, C)
         logits = torch.empty((B, ncls, H, W), dtype=torch.float32, device=dev)
-        _lib.call("segk_head_fwd", px, w2.data_ptr(), _param_f32(b).data_ptr(), logits.data_ptr(), B, H, W, Cp, C,
-                  ncls, _DT[dtype], _stream())
+        with _span("head_fwd", 2.0 * B * H * W * C * ncls, B * H * W * (C * _es(dtype) + 4 * ncls)):
+            _lib.call("segk_head_fwd", px, w2.data_ptr(), _param_f32(b).data_ptr(), logits.data_ptr(), B, H, W, Cp, C,
+                      ncls, _DT[dtype], _stream())
         ctx.dtype, ctx.dims = dtype, (B, C, H, W, ncls)
         ctx.save_for_backward(x_t, w)
         return logits
@@ -480,8 +557,9 @@ class HeadFn(torch.autograd.Function):
         part = _f32(_lib.query("segk_head_part_floats", B * H * W, Cp), dev)
         dw = torch.empty(w.shape, dtype=torch.float32, device=dev)
         db = _f32(ncls, dev)
-        _lib.call("segk_head_bwd", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(), dw.data_ptr(),
-                  db.data_ptr(), B, H, W, Cp, C, ncls, _DT[dtype], _stream())
+        with _span("head_bwd", 4.0 * B * H * W * C * ncls, B * H * W * (2 * C * _es(dtype) + 4 * ncls)):
+            _lib.call("segk_head_bwd", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(), dw.data_ptr(),
+                      db.data_ptr(), B, H, W, Cp, C, ncls, _DT[dtype], _stream())
         return None, act_view(dy, C), dw, db
 
 
@@ -514,8 +592,9 @@ class SegLossFn(torch.autograd.Function):
         ign = -1 if ignore_index is None else int(ignore_index)
         part = _f32(_lib.query("segk_loss_part_floats", N * H * W), dev)
         state = _f32(_lib.query("segk_loss_state_floats"), dev)
-        _lib.call("segk_loss_fwd", lg.data_ptr(), tg.data_ptr(), _p(cw), N, C, H * W, ign, float(smooth),
-                  float(dice_weight), float(ce_weight), part.data_ptr(), state.data_ptr(), _stream())
+        with _span("loss_fwd", 0.0, N * H * W * (4.0 * C + 8)):
+            _lib.call("segk_loss_fwd", lg.data_ptr(), tg.data_ptr(), _p(cw), N, C, H * W, ign, float(smooth),
+                      float(dice_weight), float(ce_weight), part.data_ptr(), state.data_ptr(), _stream())
         ctx.cfg = (N, C, H, W, ign, float(dice_weight), float(ce_weight))
         ctx.save_for_backward(lg, tg, cw, state)
         return state[0].clone()
@@ -526,8 +605,9 @@ class SegLossFn(torch.autograd.Function):
         N, C, H, W, ign, dw, cew = ctx.cfg
         go = gout.detach().float().reshape(1).contiguous()
         dl = torch.empty_like(lg)
-        _lib.call("segk_loss_bwd", lg.data_ptr(), tg.data_ptr(), _p(cw), state.data_ptr(), go.data_ptr(), N, C, H * W,
-                  ign, dw, cew, dl.data_ptr(), _stream())
+        with _span("loss_bwd", 0.0, N * H * W * (8.0 * C + 8)):
+            _lib.call("segk_loss_bwd", lg.data_ptr(), tg.data_ptr(), _p(cw), state.data_ptr(), go.data_ptr(), N, C,
+                      H * W, ign, dw, cew, dl.data_ptr(), _stream())
         return dl, None, None, None, None, None, None
 
 

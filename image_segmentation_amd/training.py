@@ -59,9 +59,12 @@ def train_loop(dataloader, model, loss_fn, optimizer, accumulation_steps, device
         loss = loss_fn(pred, y.squeeze(1))
 
         scaled_loss = loss / accumulation_steps
+        stepping = (batch_idx + 1) % accumulation_steps == 0 or (batch_idx + 1) == n
+        if grad_sync is not None and stepping:
+            grad_sync.arm()               # overlap the RCCL all-reduce with this backward
         scaled_loss.backward()
 
-        if (batch_idx + 1) % accumulation_steps == 0 or (batch_idx + 1) == n:
+        if stepping:
             if grad_sync is not None:
                 grad_sync.sync()
             optimizer.step()
