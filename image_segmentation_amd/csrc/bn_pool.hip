@@ -28,8 +28,34 @@ __device__ __forceinline__ Lanes lanes(int cvb, int cvec) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// stats partials [MT][C][2] (sum, sumsq of the bias-free conv output) -> scale/shift (+ running stats)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int MT, int C, int C_real,
+constexpr int NCH = 32;   // first-stage chunks of the per-tile statistics reduction
+// stage A: per-tile partials [MT][C][2] float -> [NCH][C][2] double (fixed order inside a chunk: bit-stable)
+__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __restrict__ part, int MT, int C,
+                                                              double* __restrict__ out) {
+  __shared__ double sh[8][32][2];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  const int chunk = (MT + NCH - 1) / NCH;
+  const int m0 = blockIdx.y * chunk, m1 = min(MT, m0 + chunk);
+  double s1 = 0.0, s2 = 0.0;
+  for (int m = m0 + ry; m < m1; m += 8) {
+    const float2 v = ((const float2*)part)[(size_t)m * C + c];
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+  sh[ry][cx][0] = s1;
+  sh[ry][cx][1] = s2;
+  __syncthreads();
+  if (ry == 0) {
+    s1 = 0.0; s2 = 0.0;
+    for (int r = 0; r < 8; ++r) { s1 += sh[r][cx][0]; s2 += sh[r][cx][1]; }
+    out[((size_t)blockIdx.y * C + c) * 2 + 0] = s1;
+    out[((size_t)blockIdx.y * C + c) * 2 + 1] = s2;
+  }
+}
+
+// stage B: [NCH][C][2] double partials -> scale/shift (+ running stats)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int MT, int C, int C_real,
                                                           double count, const float* conv_bias,
                                                           const float* gamma, const float* beta, float* rmean,
                                                           float* rvar, float momentum, float eps, int training,
@@ -41,9 +67,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   double s1 = 0.0, s2 = 0.0;
   if (training && c < C)
     for (int m = ry; m < MT; m += 8) {
-      const float2 v = ((const float2*)part)[(size_t)m * C + c];
-      s1 += (double)v.x;
-      s2 += (double)v.y;
+      s1 += part[((size_t)m * C + c) * 2 + 0];
+      s2 += part[((size_t)m * C + c) * 2 + 1];
     }
   sh[ry][cx][0] = s1;
   sh[ry][cx][1] = s2;
@@ -324,11 +349,19 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
       part[(size_t)blockIdx.x * C + l.cv * E::VEC + j] = a;
     }
 }
-__global__ void channel_sum_finalize_kernel(const float* __restrict__ part, int NB, int C, int C_real, float* out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C_real) return;
+__global__ __launch_bounds__(256) void channel_sum_finalize_kernel(const float* __restrict__ part, int NB, int C,
+                                                                   int C_real, float* out) {
+  __shared__ double sh[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   double s = 0.0;
-  for (int b = 0; b < NB; ++b) s += (double)part[(size_t)b * C + c];
+  if (c < C)
+    for (int b = ry; b < NB; b += 8) s += (double)part[(size_t)b * C + c];
+  sh[ry][cx] = s;
+  __syncthreads();
+  if (ry != 0 || c >= C_real) return;
+  s = 0.0;
+  for (int r = 0; r < 8; ++r) s += sh[r][cx];
   out[c] = (float)s;
 }
 
@@ -349,11 +382,18 @@ int segk_bn_finalize_impl(const float* part, int MT, int C, int C_real, double c
   SEGK_REQUIRE(gamma && beta && scale && shift, "bn_finalize: null pointer");
   if (training) SEGK_REQUIRE(part && MT > 0 && count > 0 && mean && rstd, "bn_finalize: training needs partials");
   else SEGK_REQUIRE(rmean && rvar, "bn_finalize: eval needs running statistics");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 32), dim3(256), 0, st, part, MT, C, C_real, count, conv_bias, gamma,
-                     beta, rmean, rvar, momentum, eps, training, scale, shift, mean, rstd);
+  // the stats buffer carries NCH*C*2 doubles of scratch behind the [MT][C][2] float partials
+  double* scratch = part ? (double*)(const_cast<float*>(part) + (size_t)MT * C * 2) : nullptr;
+  if (training) {
+    hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3(C / 32, NCH), dim3(256), 0, st, part, MT, C, scratch);
+    SEGK_CHECK_LAUNCH("bn_stats_reduce");
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 32), dim3(256), 0, st, scratch, NCH, C, C_real, count, conv_bias,
+                     gamma, beta, rmean, rvar, momentum, eps, training, scale, shift, mean, rstd);
   SEGK_CHECK_LAUNCH("bn_finalize");
   return 0;
 }
+int segk_bn_stats_floats(int tiles, int Cp) { return tiles * Cp * 2 + NCH * Cp * 4; }
 
 template <typename T>
 static int bn_relu_apply_t(const void* z, void* y, const float* scale, const float* shift, long P, int C, hipStream_t st) {
@@ -378,7 +418,7 @@ int segk_bn_bwd_blocks(long P, int C, int dtype) {
   int cvb, rows, gy;
   lane_geometry(C, vec, &cvb, &rows, &gy);
   long gx = (P + rows - 1) / rows;
-  if (gx > 1024) gx = 1024;
+  if (gx > 512) gx = 512;      // enough blocks to fill the chip; keeps the finalize pass short
   return (int)gx;
 }
 
@@ -458,7 +498,7 @@ int segk_channel_sum_impl(const void* x, long P, int C, int C_real, float* part,
   else
     hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(gx, gy), dim3(256), lds, st, (const float*)x, P, C, cvb, rows, part);
   SEGK_CHECK_LAUNCH("channel_sum");
-  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(cdiv(C_real, 256)), dim3(256), 0, st, part, gx, C, C_real, out);
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C / 32), dim3(256), 0, st, part, gx, C, C_real, out);
   SEGK_CHECK_LAUNCH("channel_sum_finalize");
   return 0;
 }

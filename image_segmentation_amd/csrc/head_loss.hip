@@ -169,14 +169,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
-__global__ void head_bwd_finalize_kernel(const float* __restrict__ part, int NB, int Cp, int C, int ncls,
-                                         float* __restrict__ dw, float* __restrict__ db) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// one 64-lane wave per output element: lanes stride the NB block partials, fixed-order tree reduce
+__global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ part, int NB, int Cp, int C,
+                                                                int ncls, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= ncls * (C + 1)) return;
   const int k = i / (C + 1), c = i - k * (C + 1);
   const int col = (c == C) ? Cp : c;
   double s = 0.0;
-  for (int b = 0; b < NB; ++b) s += (double)part[(size_t)b * MAXC * (Cp + 1) + k * (Cp + 1) + col];
+  for (int b = lane; b < NB; b += 64) s += (double)part[(size_t)b * MAXC * (Cp + 1) + k * (Cp + 1) + col];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane != 0) return;
   if (c == C) db[k] = (float)s;
   else dw[(size_t)k * C + c] = (float)s;
 }
@@ -241,13 +246,22 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
 
 // state: [0]=loss [1]=ce [2]=dice(-mean dc) [3]=ce_den, [4..4+MAXC) dc, [.. ) den_raw(Sp+Sg+smooth), [..) a_k
 constexpr int LS = 4 + 3 * MAXC;
-__global__ void loss_finalize_kernel(const float* __restrict__ part, int NB, int C, const float* cw, int ignore_index,
-                                     float smooth, float dice_weight, float ce_weight, float* __restrict__ state) {
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int NB, int C,
+                                                            const float* cw, int ignore_index, float smooth,
+                                                            float dice_weight, float ce_weight,
+                                                            float* __restrict__ state) {
   __shared__ double tot[LP];
-  const int t = threadIdx.x;
+  __shared__ double sh[8][32];
+  static_assert(LP <= 32, "one column lane per partial");
+  const int t = threadIdx.x, cx = t & 31, ry = t >> 5;
+  double acc = 0.0;
+  if (cx < LP)
+    for (int b = ry; b < NB; b += 8) acc += (double)part[(size_t)b * LP + cx];
+  sh[ry][cx] = acc;
+  __syncthreads();
   if (t < LP) {
     double s = 0.0;
-    for (int b = 0; b < NB; ++b) s += (double)part[(size_t)b * LP + t];
+    for (int r = 0; r < 8; ++r) s += sh[r][t];   // fixed order
     tot[t] = s;
   }
   __syncthreads();
@@ -364,7 +378,7 @@ static bool raise_lds(const void* f) {
 // ------------------------------------------------------------------------------------------------
 int segk_head_blocks(long P) {
   long g = (P + HT - 1) / HT;
-  return (int)(g > 512 ? 512 : g);
+  return (int)(g > 256 ? 256 : g);
 }
 int segk_head_part_floats(long P, int Cp) { return segk_head_blocks(P) * MAXC * (Cp + 1); }
 
@@ -399,14 +413,14 @@ int segk_head_bwd_impl(const float* dlog, const void* y, const float* w, void* d
     hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(nb), dim3(256), head_lds<float>(), st, dlog, (const float*)y, w, (float*)dy, part, P, HW, Cp, C, ncls);
   }
   SEGK_CHECK_LAUNCH("head_bwd");
-  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(ncls * (C + 1), 256)), dim3(256), 0, st, part, nb, Cp, C, ncls, dw, db);
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(ncls * (C + 1), 4)), dim3(256), 0, st, part, nb, Cp, C, ncls, dw, db);
   SEGK_CHECK_LAUNCH("head_bwd_finalize");
   return 0;
 }
 
 int segk_loss_blocks(long P) {
   long g = (P + 255) / 256;
-  return (int)(g > 1024 ? 1024 : g);
+  return (int)(g > 512 ? 512 : g);
 }
 int segk_loss_part_floats(long P) { return segk_loss_blocks(P) * LP; }
 int segk_loss_state_floats(void) { return LS; }
@@ -420,7 +434,7 @@ int segk_loss_fwd_impl(const float* logits, const long long* labels, const float
   const int nb = segk_loss_blocks(P);
   hipLaunchKernelGGL(loss_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part);
   SEGK_CHECK_LAUNCH("loss_fwd");
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, part, nb, C, cw, ignore_index, smooth, dice_weight, ce_weight, state);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, nb, C, cw, ignore_index, smooth, dice_weight, ce_weight, state);
   SEGK_CHECK_LAUNCH("loss_finalize");
   return 0;
 }

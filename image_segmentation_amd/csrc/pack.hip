@@ -98,18 +98,20 @@ __global__ void pack_convt_weight_kernel(const float* __restrict__ w, T* __restr
 //  kind 1: ConvTranspose IOHW grad[n=ci][k=co][tap]   (no dual map)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, float* __restrict__ grad, int N, int CA,
                                     int CB, int Np, int CAp, int CBp, int taps, int kind) {
+  // one thread per OUTPUT element (coalesced stores); the strided slab reads are absorbed by L2
   const int Kp = CAp + CBp, K = CA + CB;
   const long slab = (long)Np * taps * Kp;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < slab; i += (long)gridDim.x * 256) {
-    const int kp = (int)(i % Kp);
-    long r = i / Kp;
-    const int tap = (int)(r % taps);
-    const int n = (int)(r / taps);
-    const int k = dual_map(kp, CA, CAp, CB, CBp);
-    if (n >= N || k < 0) continue;
+  const long total = (long)N * K * taps;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int tap = (int)(i % taps);
+    long r = i / taps;
+    const int k = (int)(r % K);
+    const int n = (int)(r / K);
+    const int kp = k < CA ? k : CAp + (k - CA);
+    const long src = ((long)n * taps + tap) * Kp + kp;
     float s = 0.f;
-    for (int t = 0; t < S; ++t) s += slabs[(long)t * slab + i];  // fixed order: bit-stable
-    grad[((long)n * K + k) * taps + tap] = s;
+    for (int t = 0; t < S; ++t) s += slabs[(long)t * slab + src];  // fixed order: bit-stable
+    grad[i] = s;
     (void)kind;
   }
 }
@@ -182,8 +184,8 @@ int segk_wgrad_reduce_impl(const float* slabs, int S, float* grad, int N, int CA
                            int taps, hipStream_t st) {
   SEGK_REQUIRE(slabs && grad && S > 0 && N > 0 && CA > 0 && CB >= 0 && Np >= N && CAp >= CA && CBp >= CB && taps > 0,
                "wgrad_reduce: bad arguments");
-  const long slab = (long)Np * taps * (CAp + CBp);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(slab)), dim3(256), 0, st, slabs, S, grad, N, CA, CB, Np, CAp,
+  const long total = (long)N * (CA + CB) * taps;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, st, slabs, S, grad, N, CA, CB, Np, CAp,
                      CBp, taps, 0);
   SEGK_CHECK_LAUNCH("wgrad_reduce");
   return 0;

@@ -234,7 +234,7 @@ def wgrad(dz_ptr, CDp, ptrA, CAp, ptrB, CBp, B, H, W, geo, dtype, dev, scale=Non
     wc = 2 if CDp % 64 == 0 else 1
     wi = 2 if (CAp % 64 == 0 and CBp % 64 == 0) else 1
     nct = (CDp // (32 * wc)) * ((CAp + CBp) // (32 * wi))
-    S = max(1, min(tiles, 1024 // nct if nct < 1024 else 1))
+    S = max(1, min(tiles, 512 // nct if nct < 512 else 1))
     slabs = _f32(S * CDp * taps * (CAp + CBp), dev)
     tag = {0: "wgrad3x3", 1: "wgrad1x1", 2: "wgrad_convt"}[geo]
     with _span(tag, 2.0 * P * taps * cd * ck, (P * cd + pk * ck) * e + 4.0 * taps * cd * ck):
@@ -319,14 +319,14 @@ class DoubleConvFn(torch.autograd.Function):
         P = B * H * W
 
         z1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        st1 = _f32(tiles * Coutp * 2, dev) if training else None
+        st1 = _f32(_lib.query("segk_bn_stats_floats", tiles, Coutp), dev) if training else None
         conv3x3(xa_t, pA, CAp, pB, CBp, w1p, z1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, stats=st1, alg=(CA + CB, Cout))
         mom1 = bn1.momentum if bn1.momentum is not None else 0.1
         sc1, sh1, mu1, rs1 = bn_finalize(st1, tiles, Cout, P, None if b1 is None else _param_f32(b1), _param_f32(g1),
                                          _param_f32(be1), bn1.running_mean, bn1.running_var, mom1, bn1.eps, training,
                                          dev)
         z2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        st2 = _f32(tiles * Coutp * 2, dev) if training else None
+        st2 = _f32(_lib.query("segk_bn_stats_floats", tiles, Coutp), dev) if training else None
         conv3x3(z1, z1.data_ptr(), Coutp, 0, 0, w2p, z2.data_ptr(), Coutp, 0, 0, B, H, W, dtype, scale=sc1, shift=sh1,
                 stats=st2, alg=(Cout, Cout))
         mom2 = bn2.momentum if bn2.momentum is not None else 0.1

@@ -55,6 +55,8 @@ int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cin
  * stats != NULL: per-tile per-channel (sum, sumsq) partials [segk_conv_tiles()][CO1+CO2][2] for
  * training-mode BatchNorm (finish with segk_bn_finalize).  For the data gradient pass mode-1 weights. */
 int segk_conv_tiles(int B, int H, int W);
+/* floats to allocate for `stats`: the [tiles][Cp][2] partials plus the scratch segk_bn_finalize reduces through */
+int segk_bn_stats_floats(int tiles, int Cp);
 int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const float* bias, const float* scale,
                  const float* shift, void* out, void* out2, float* stats, int B, int H, int W, int CA, int CB,
                  int CO1, int CO2, int dtype, segk_stream_t s);
