@@ -28,13 +28,7 @@ int segk_loss_bwd_impl(const float*, const long long*, const float*, const float
                        float, float, float*, hipStream_t);
 int segk_confusion_impl(const float*, const long long*, int, int, long, unsigned long long*, hipStream_t);
 
-static inline int tile_twl(int W) { return W > 16 ? 5 : 4; }   // 8x32 tiles unless the image is <= 16 wide
-
-static void fill_tiles(ConvArgs& a) {
-  a.twl = tile_twl(a.W);
-  a.tiles_x = cdiv(a.W, 1 << a.twl);
-  a.tiles_y = cdiv(a.H, 256 >> a.twl);
-}
+static void fill_tiles(ConvArgs&) {}   // tile geometry is chosen per kernel configuration by the launcher
 
 extern "C" {
 
@@ -56,9 +50,9 @@ int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cin
   return segk_pack_convt_weight_impl(w, dst, Cin, Cout, Cinp, Coutp, mode, dtype, (hipStream_t)s);
 }
 
-int segk_conv_tiles(int B, int H, int W) {
-  const int twl = tile_twl(W);
-  return B * cdiv(W, 1 << twl) * cdiv(H, 256 >> twl);
+int segk_conv_tiles(int B, int H, int W, int Cout) {
+  const int bm = segk_conv_bm(0, Cout), twl = segk_conv_twl(bm, W);
+  return B * cdiv(W, 1 << twl) * cdiv(H, bm >> twl);
 }
 
 int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const float* bias, const float* scale,

@@ -17,8 +17,13 @@
 // Epilogue: optional bias, per-channel sum / sum-of-squares partials for training-mode BatchNorm taken
 // from the fp32 accumulators (deterministic per-tile partials, no atomics), LDS transpose, 16-byte
 // coalesced NHWC stores (optionally split over two destinations, or pixel-shuffled for ConvTranspose).
+#include <type_traits>
 #include "common.hpp"
 #include "segk_internal.h"
+
+// pixel-tile geometry shared by the launcher and the BN-statistics sizing query (api.hip)
+int segk_conv_bm(int geo, int unit) { return (unit % 128 == 0 || geo != 0) ? 256 : 128; }
+int segk_conv_twl(int bm, int W) { return bm == 128 ? 4 : (W > 16 ? 5 : 4); }   // 8x16 | 8x32 | 16x16 tiles
 
 namespace {
 
@@ -41,25 +46,32 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int GEO, int WM, int WN, int MF, int NF>
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
+template <int V> using IC = std::integral_constant<int, V>;
+
+// Tile: BM = WM*MF*32 output pixels (TH x TW) by BN = WN*NF*32 output channels, WM*WN waves.
+// PBUF: patch buffers (2 = next chunk staged under the current chunk's MFMAs; 1 = smaller LDS footprint so
+// that three 4-wave workgroups share a CU and overlap each other's load / MFMA / store phases).
+template <typename T, int GEO, int WM, int WN, int MF, int NF, int PBUF>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs a) {
   using E = ET<T>;
-  constexpr int BN = WN * NF * 32;
+  constexpr int NW = WM * WN, NTHR = NW * 64;
+  constexpr int BM = WM * MF * 32, BN = WN * NF * 32;
   constexpr int NTAPS = (GEO == 0) ? 9 : 1;
   constexpr int TPS = (GEO == 0) ? 3 : 1;   // taps per pipeline step (one kernel row)
   constexpr int SPC = (GEO == 0) ? 3 : 1;   // steps per channel chunk
   constexpr int HALO = (GEO == 0) ? 1 : 0;
-  constexpr int NPL = (GEO == 0) ? 3 : 2;   // patch 16-byte pieces per thread per chunk
+  constexpr int NPL = (GEO == 0) ? (BM == 256 ? 3 : 4) : (BM * 4 + NTHR - 1) / NTHR;  // patch pieces / thread
   constexpr int NWP = TPS * BN * 4;         // weight 16-byte pieces per step
-  constexpr int NWL = (NWP + 511) / 512;
-  static_assert(WM * WN == 8 && WM * MF * 32 == 256, "tile is 256 pixels x BN, 8 waves");
+  constexpr int NWL = (NWP + NTHR - 1) / NTHR;
+  static_assert(BM == 256 || BM == 128, "pixel tile is 256 or 128");
+  static_assert(NTHR % 4 == 0, "a thread keeps one 16-byte slot of the 64-byte chunk");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int lr = lane & 31, lh = lane >> 5;
 
-  const int twl = a.twl, tw = 1 << twl, th = 256 >> twl;
+  const int twl = a.twl, tw = 1 << twl, th = BM >> twl;
   const int PW = tw + 2 * HALO, PH = th + 2 * HALO;
   const int ROWP = (PW * PIXB + 255) & ~255;
   const int PB = PH * ROWP;
@@ -78,13 +90,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int H = a.H, W = a.W;
 
   // ---- per-thread staging assignment (chunk-invariant)
-  const int pc = tid & 3;  // 16-byte slot inside the 64-byte chunk (512 % 4 == 0: same for every piece)
+  const int pc = tid & 3;  // 16-byte slot inside the 64-byte chunk (NTHR % 4 == 0: same for every piece)
   int ppix[NPL], plds[NPL];
   {
     const int NP = PH * PW * 4;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      const int q = tid + i * 512;
+      const int q = tid + i * NTHR;
       plds[i] = -1;
       ppix[i] = -1;
       if (q < NP) {
@@ -100,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
   int wsrc[NWL], wlds[NWL];
 #pragma unroll
   for (int i = 0; i < NWL; ++i) {
-    const int q = tid + i * 512;
+    const int q = tid + i * NTHR;
     wsrc[i] = -1;
     wlds[i] = -1;
     if (q < NWP) {
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int nsteps = nchunks * SPC;
   const bool pro = (a.scale != nullptr);
 
-  uint4 preg[NPL], wreg[NWL];
+  uint4 preg[NPL], wreg[2][NWL];
   float psc[E::VEC], psh[E::VEC];
 
   auto load_patch = [&](int kc) {
@@ -163,20 +175,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
       }
     }
   };
-  auto load_w = [&](int s) {
+  auto load_w = [&](int s, uint4 (&wr)[NWL]) {
     const int kc = s / SPC, tg = s - kc * SPC;
     const char* wb = (const char*)a.w + ((size_t)(kc * NTAPS + tg * TPS) * a.Ntot + n0) * 64;
 #pragma unroll
     for (int i = 0; i < NWL; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (wsrc[i] >= 0) v = *(const uint4*)(wb + wsrc[i]);
-      wreg[i] = v;
+      wr[i] = v;
     }
   };
-  auto store_w = [&](char* wbuf) {
+  auto store_w = [&](char* wbuf, const uint4 (&wr)[NWL]) {
 #pragma unroll
     for (int i = 0; i < NWL; ++i)
-      if (wlds[i] >= 0) *(uint4*)(wbuf + wlds[i]) = wreg[i];
+      if (wlds[i] >= 0) *(uint4*)(wbuf + wlds[i]) = wr[i];
   };
 
   // ---- per-lane fragment addresses
@@ -198,48 +210,95 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
 
   char* const patch0 = smem;
-  char* const wbuf0 = smem + 2 * PB;
+  char* const wbuf0 = smem + PBUF * PB;
 
-  // ---- prologue: stage chunk 0 / step 0
-  load_patch(0);
-  load_w(0);
-  store_patch(patch0);
-  store_w(wbuf0);
-  __syncthreads();
-
-  for (int s = 0; s < nsteps; ++s) {
-    const int kc = s / SPC, tg = s - kc * SPC;
-    const bool has_next = (s + 1 < nsteps);
-    const bool next_chunk = has_next && (tg == SPC - 1);
-    if (has_next) load_w(s + 1);          // global loads fly under the MFMAs below
-    if (next_chunk) load_patch(kc + 1);
-
-    const char* pb = patch0 + (kc & 1) * PB + tg * ROWP * (GEO == 0 ? 1 : 0);
-    const char* wb = wbuf0 + (s & 1) * WB;
+  // one tap (two MFMA k-steps over the 64-byte chunk) against LDS
+  auto mma_tap = [&](const char* pb, const char* wb) {
 #pragma unroll
-    for (int t = 0; t < TPS; ++t) {
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 fa[MF], fb[NF];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        uint4 fa[MF], fb[NF];
+      for (int mf = 0; mf < MF; ++mf) fa[mf] = *(const uint4*)(pb + laneA[mf] + kk * 32);
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) fa[mf] = *(const uint4*)(pb + laneA[mf] + t * PIXB + kk * 32);
+      for (int nf = 0; nf < NF; ++nf) fb[nf] = *(const uint4*)(wb + laneB[nf] + kk * 32);
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) fb[nf] = *(const uint4*)(wb + t * (BN * PIXB) + laneB[nf] + kk * 32);
+      for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-          for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[mf], fb[nf], acc[mf][nf]);
-      }
+        for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[mf], fb[nf], acc[mf][nf]);
     }
-    if (has_next) store_w(wbuf0 + ((s + 1) & 1) * WB);
-    if (next_chunk) store_patch(patch0 + ((kc + 1) & 1) * PB);
+  };
+
+  if constexpr (GEO == 0) {
+    // Software pipeline, weights two steps ahead: at step s the registers of parity (s+1)&1 hold step s+1's
+    // weight tile (loaded during step s-1) and are written to LDS BETWEEN this step's MFMA groups, while
+    // the loads of step s+2 are issued into the other register set.  One barrier per step.
+    load_patch(0);
+    load_w(0, wreg[0]);
+    store_patch(patch0);
+    store_w(wbuf0, wreg[0]);
+    if (nsteps > 1) load_w(1, wreg[1]);
     __syncthreads();
+
+    auto do_step = [&](auto TGc, auto PARc, int kc) {
+      constexpr int TG = decltype(TGc)::value, PAR = decltype(PARc)::value;
+      const int s = kc * 3 + TG;
+      const bool more_chunks = (kc + 1 < nchunks);
+      if (s + 2 < nsteps) load_w(s + 2, wreg[PAR]);
+      if (TG == 0 && more_chunks) load_patch(kc + 1);
+      const char* pb = patch0 + (PBUF == 2 ? (kc & 1) * PB : 0) + TG * ROWP;
+      const char* wb = wbuf0 + PAR * WB;
+      mma_tap(pb, wb);
+      if (s + 1 < nsteps) store_w(wbuf0 + (PAR ^ 1) * WB, wreg[PAR ^ 1]);
+      mma_tap(pb + PIXB, wb + BN * PIXB);
+      if (TG == 2 && PBUF == 2 && more_chunks) store_patch(patch0 + ((kc + 1) & 1) * PB);
+      mma_tap(pb + 2 * PIXB, wb + 2 * BN * PIXB);
+      __syncthreads();
+      if (TG == 2 && PBUF == 1 && more_chunks) {
+        store_patch(patch0);
+        __syncthreads();
+      }
+    };
+    int kc = 0;
+    for (; kc + 1 < nchunks; kc += 2) {   // six steps: register/LDS parities are compile-time constants
+      do_step(IC<0>{}, IC<0>{}, kc);
+      do_step(IC<1>{}, IC<1>{}, kc);
+      do_step(IC<2>{}, IC<0>{}, kc);
+      do_step(IC<0>{}, IC<1>{}, kc + 1);
+      do_step(IC<1>{}, IC<0>{}, kc + 1);
+      do_step(IC<2>{}, IC<1>{}, kc + 1);
+    }
+    if (kc < nchunks) {
+      do_step(IC<0>{}, IC<0>{}, kc);
+      do_step(IC<1>{}, IC<1>{}, kc);
+      do_step(IC<2>{}, IC<0>{}, kc);
+    }
+  } else {
+    // 1x1 geometry: one tap per chunk; patch + weights staged one step ahead
+    load_patch(0);
+    load_w(0, wreg[0]);
+    store_patch(patch0);
+    store_w(wbuf0, wreg[0]);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const bool has_next = (s + 1 < nsteps);
+      if (has_next) {
+        load_w(s + 1, wreg[0]);
+        load_patch(s + 1);
+      }
+      mma_tap(patch0 + (PBUF == 2 ? (s & 1) * PB : 0), wbuf0 + (s & 1) * WB);
+      if (PBUF == 1) __syncthreads();
+      if (has_next) {
+        store_w(wbuf0 + ((s + 1) & 1) * WB, wreg[0]);
+        store_patch(patch0 + (PBUF == 2 ? ((s + 1) & 1) * PB : 0));
+      }
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: bias, BN statistics from fp32 accumulators, LDS transpose, coalesced store
   constexpr int OP = BN * E::ES + 16;
   char* const ot = smem;
-  float* const red = (float*)(smem + 256 * OP);
+  float* const red = (float*)(smem + BM * OP);
   const bool do_stats = (a.stats != nullptr);
   float s1[NF], s2[NF];
 #pragma unroll
@@ -287,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
     *dst = make_float2(t1, t2);
   }
   constexpr int CPR = BN * E::ES / 16;
-  for (int q = tid; q < 256 * CPR; q += 512) {
+  for (int q = tid; q < BM * CPR; q += NTHR) {
     const int m = q / CPR, cc = q - m * CPR;
     const int ty = m >> twl, tx = m & (tw - 1);
     if (y0 + ty >= H || x0 + tx >= W) continue;
@@ -307,28 +366,31 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
-template <typename T, int GEO, int WM, int WN, int MF, int NF>
-int launch_cfg(const ConvArgs& a, hipStream_t st) {
+template <typename T, int GEO, int WM, int WN, int MF, int NF, int PBUF>
+int launch_cfg(ConvArgs a, hipStream_t st) {
   using E = ET<T>;
-  constexpr int BN = WN * NF * 32;
+  constexpr int BM = WM * MF * 32, BN = WN * NF * 32, NTHR = WM * WN * 64;
   constexpr int HALO = (GEO == 0) ? 1 : 0;
   constexpr int TPS = (GEO == 0) ? 3 : 1;
-  const int tw = 1 << a.twl, th = 256 >> a.twl;
+  a.twl = segk_conv_twl(BM, a.W);
+  const int tw = 1 << a.twl, th = BM >> a.twl;
+  a.tiles_x = cdiv(a.W, tw);
+  a.tiles_y = cdiv(a.H, th);
   const int PW = tw + 2 * HALO, PH = th + 2 * HALO;
   const int ROWP = (PW * PIXB + 255) & ~255;
-  const size_t main_b = 2 * (size_t)PH * ROWP + 2 * (size_t)TPS * BN * PIXB;
-  const size_t epi_b = 256 * (size_t)(BN * E::ES + 16) + (size_t)WM * BN * 8;
+  const size_t main_b = PBUF * (size_t)PH * ROWP + 2 * (size_t)TPS * BN * PIXB;
+  const size_t epi_b = BM * (size_t)(BN * E::ES + 16) + (size_t)WM * BN * 8;
   const size_t lds = main_b > epi_b ? main_b : epi_b;
   SEGK_REQUIRE(lds <= 160 * 1024, "conv_igemm: LDS %zu exceeds 160 KiB", lds);
   const int grid = a.B * a.tiles_x * a.tiles_y * (a.Ntot / BN);
-  auto kern = conv_igemm_kernel<T, GEO, WM, WN, MF, NF>;
+  auto kern = conv_igemm_kernel<T, GEO, WM, WN, MF, NF, PBUF>;
   static bool attr_set = false;  // idempotent; racing setters write the same value
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SEGK_FAIL(-3, "conv_igemm: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, st, a);
   SEGK_CHECK_LAUNCH("conv_igemm");
   return 0;
 }
@@ -337,9 +399,14 @@ template <typename T, int GEO>
 int launch_geo(const ConvArgs& a, hipStream_t st) {
   // BN must divide N; with the pixel-shuffle store a channel tile must not straddle two taps.
   const int unit = a.shuffle ? a.CO1 : a.Ntot;
-  if (unit % 128 == 0) return launch_cfg<T, GEO, 4, 2, 2, 2>(a, st);
-  if (unit % 64 == 0) return launch_cfg<T, GEO, 4, 2, 2, 1>(a, st);
-  return launch_cfg<T, GEO, 8, 1, 1, 1>(a, st);
+  if (unit % 128 == 0) return launch_cfg<T, GEO, 4, 2, 2, 2, 2>(a, st);            // 256 px x 128 ch, 8 waves
+  if constexpr (GEO == 0) {
+    if (unit % 64 == 0) return launch_cfg<T, GEO, 2, 2, 2, 1, 1>(a, st);           // 128 px x 64 ch, 4 waves
+    return launch_cfg<T, GEO, 4, 1, 1, 1, 1>(a, st);                               // 128 px x 32 ch, 4 waves
+  } else {
+    if (unit % 64 == 0) return launch_cfg<T, GEO, 4, 2, 2, 1, 2>(a, st);
+    return launch_cfg<T, GEO, 8, 1, 1, 1, 2>(a, st);
+  }
 }
 
 }  // namespace
@@ -361,8 +428,6 @@ int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st
   SEGK_REQUIRE(a.CO1 > 0 && a.CO1 % 32 == 0 && a.CO2 >= 0 && a.CO2 % 32 == 0, "conv_igemm: bad output channels");
   if (a.shuffle) SEGK_REQUIRE(a.Ntot == 4 * a.CO1 && !a.out2 && geo == 1, "conv_igemm: pixel-shuffle needs N=4*Cout");
   else SEGK_REQUIRE(a.Ntot == a.CO1 + a.CO2 && (a.CO2 == 0) == (a.out2 == nullptr), "conv_igemm: N != CO1+CO2");
-  SEGK_REQUIRE(a.twl == 4 || a.twl == 5, "conv_igemm: tile width must be 16 or 32");
-  SEGK_REQUIRE(a.tiles_x == cdiv(a.W, 1 << a.twl) && a.tiles_y == cdiv(a.H, 256 >> a.twl), "conv_igemm: tile grid mismatch");
   SEGK_REQUIRE((long long)a.B * a.H * a.W * 4 < 2147483647LL, "conv_igemm: pixel index overflows int32");
   if (dtype == SEGK_DT_BF16) return geo == 0 ? launch_geo<bf16_t, 0>(a, st) : launch_geo<bf16_t, 1>(a, st);
   return geo == 0 ? launch_geo<float, 0>(a, st) : launch_geo<float, 1>(a, st);

@@ -20,6 +20,8 @@ struct ConvArgs {
   int unshuf, shuffle;
 };
 int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st);
+int segk_conv_bm(int geo, int unit);      // pixels per tile for a layer with N = unit output channels
+int segk_conv_twl(int bm, int W);         // log2 tile width
 
 struct WgradArgs {
   const void* dz;       // NHWC [B,H,W,CD]        (un-shifted operand; rows of dW)

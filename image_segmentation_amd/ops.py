@@ -315,7 +315,7 @@ class DoubleConvFn(torch.autograd.Function):
         xb_t, pB, CBp = (None, 0, 0) if xb is None else _raw(xb, dtype)
         w1p = mod.cache.get(("w1f", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 0))
         w2p = mod.cache.get(("w2f", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 0))
-        tiles = _lib.query("segk_conv_tiles", B, H, W)
+        tiles = _lib.query("segk_conv_tiles", B, H, W, Coutp)
         P = B * H * W
 
         z1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)

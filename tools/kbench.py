@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single kernels at U-Net layer shapes (B=32, 256x256 input): conv3x3 forward /
+weight-gradient through the C ABI.  Usage: python tools/kbench.py [conv|wgrad|all] [--iters N]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from image_segmentation_amd import ops, _lib
+
+LAYERS = [  # name, Cin, Cout, HW   (B = 32)
+    ("64->64@256", 64, 64, 256), ("128->64@256", 128, 64, 256), ("64->128@256(dgrad up4)", 64, 128, 256),
+    ("128->128@128", 128, 128, 128), ("256->256@64", 256, 256, 64), ("512->512@32", 512, 512, 32),
+    ("1024->1024@16", 1024, 1024, 16), ("3->64@256", 32, 64, 256),
+]
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--pro", action="store_true")
+    args = ap.parse_args()
+    dt = torch.bfloat16
+    B = 32
+    for name, cin, cout, hw in LAYERS:
+        if args.only and args.only not in name:
+            continue
+        x = torch.randn((B, hw, hw, cin), device="cuda").to(dt)
+        g = torch.randn((B, hw, hw, cout), device="cuda").to(dt)
+        w = torch.randn((cout, cin, 3, 3), device="cuda") / (3 * cin ** 0.5)
+        wp = ops.pack_conv(w, cin, 0, dt, 0)
+        out = torch.empty((B, hw, hw, cout), dtype=dt, device="cuda")
+        sc = torch.rand(cin, device="cuda") + 0.5 if args.pro else None
+        sh = torch.rand(cin, device="cuda") - 0.5 if args.pro else None
+        fl = 2.0 * B * hw * hw * 9 * cin * cout
+        by = B * hw * hw * (cin + cout) * 2
+        if args.what in ("conv", "all"):
+            tiles = _lib.query("segk_conv_tiles", B, hw, hw, cout)
+            st = torch.empty((_lib.query("segk_bn_stats_floats", tiles, cout),), dtype=torch.float32, device="cuda")
+            us = timeit(lambda: ops.conv3x3(x, x.data_ptr(), cin, 0, 0, wp, out.data_ptr(), cout, 0, 0, B, hw, hw, dt,
+                                            scale=sc, shift=sh, stats=st), args.iters)
+            print(f"conv  {name:26s} {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {by/us/1e3:7.1f} GB/s(alg)")
+        if args.what in ("wgrad", "all"):
+            def f():
+                ops.wgrad(g.data_ptr(), cout, x.data_ptr(), cin, 0, 0, B, hw, hw, 0, dt, "cuda", scale=sc, shift=sh)
+            us = timeit(f, args.iters)
+            print(f"wgrad {name:26s} {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {by/us/1e3:7.1f} GB/s(alg)")
+
+
+if __name__ == "__main__":
+    main()
