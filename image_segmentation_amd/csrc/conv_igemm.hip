@@ -7,13 +7,20 @@
 //                                          (unet.py:59, clipunet.py:83), its data-gradient as a 2x2
 //                                          un-shuffle gather GEMM, and the CLIP 1x1 projections (clipunet.py:84,122)
 //
-// GEMM view: M = 256 output pixels of one spatial tile (16x16 or 8x32), N = BN output channels,
-// K = taps x Cin.  The input patch (tile + halo) of one 64-byte channel chunk is staged ONCE into LDS
-// and reused by all 9 taps as shifted row addresses (the 3x3 im2col never exists); weight tiles stream
-// through a second double-buffered LDS region.  Staging is register-staged (global -> VGPR -> LDS,
-// issue-early / write-late) so the previous layer's BatchNorm+ReLU can be applied on the fly
-// (prologue fusion) and so out-of-image halo pixels become exact zeros.  MFMA: bf16 32x32x16 or exact
-// fp32 32x32x2 with a byte-identical LDS image (a 16-byte fragment read is 8 bf16 k-values or 4 fp32).
+// GEMM view: M = BM output pixels of one spatial tile (TH x TW), N = BN output channels, K = taps x Cin.
+// The input patch (tile + halo) of one 64-byte channel chunk is staged ONCE into LDS and reused by all 9
+// taps as shifted row addresses (the 3x3 im2col never exists); weight tiles stream through a second,
+// double-buffered LDS region.  Staging is register-staged (global -> VGPR -> LDS, issue-early /
+// write-late) so the previous layer's BatchNorm+ReLU can be applied on the fly (prologue fusion) and so
+// out-of-image halo pixels become exact zeros.  MFMA: bf16 32x32x16 or exact fp32 32x32x2 with a
+// byte-identical LDS image (a 16-byte fragment read is 8 bf16 k-values or 4 fp32).
+//
+// The kernel is PERSISTENT over work units (pixel tile x channel tile): every XCD owns a contiguous range
+// of units (neighbouring tiles share halos and weights through that XCD's L2), each workgroup walks its
+// XCD's range with a fixed stride, and the loads of the next unit's first patch chunk / weight step are
+// issued under the current unit's last MFMA steps, so the HBM latency of a tile start hides behind the
+// previous tile's tail and the per-thread addressing set-up is paid once per workgroup, not per tile.
+//
 // Epilogue: optional bias, per-channel sum / sum-of-squares partials for training-mode BatchNorm taken
 // from the fp32 accumulators (deterministic per-tile partials, no atomics), LDS transpose, 16-byte
 // coalesced NHWC stores (optionally split over two destinations, or pixel-shuffled for ConvTranspose).
@@ -26,6 +33,8 @@ int segk_conv_bm(int geo, int unit) { return (unit % 128 == 0 || geo != 0) ? 256
 int segk_conv_twl(int bm, int W) { return bm == 128 ? 4 : (W > 16 ? 5 : 4); }   // 8x16 | 8x32 | 16x16 tiles
 
 namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (SSA)
 
 constexpr int PIXB = 80;  // LDS pitch of one pixel's 64-byte K-chunk: +16 B pad -> conflict-free ds_read_b128
 
@@ -46,12 +55,21 @@ template <> struct Mma<float> {
   }
 };
 
-template <int V> using IC = std::integral_constant<int, V>;
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n < 8) n = 256;
+  }
+  return n;
+}
 
-// Tile: BM = WM*MF*32 output pixels (TH x TW) by BN = WN*NF*32 output channels, WM*WN waves.
+// Tile: BM = WM*MF*32 output pixels (TH x TW, TW = 1 << TWL) by BN = WN*NF*32 output channels, WM*WN waves.
 // PBUF: patch buffers (2 = next chunk staged under the current chunk's MFMAs; 1 = smaller LDS footprint so
-// that three 4-wave workgroups share a CU and overlap each other's load / MFMA / store phases).
-template <typename T, int GEO, int WM, int WN, int MF, int NF, int PBUF>
+// that two or three 4-wave workgroups share a CU and overlap each other's load / MFMA / store phases).
+template <typename T, int GEO, int TWL, int WM, int WN, int MF, int NF, int PBUF, bool PRO>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs a) {
   using E = ET<T>;
   constexpr int NW = WM * WN, NTHR = NW * 64;
@@ -60,77 +78,99 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   constexpr int TPS = (GEO == 0) ? 3 : 1;   // taps per pipeline step (one kernel row)
   constexpr int SPC = (GEO == 0) ? 3 : 1;   // steps per channel chunk
   constexpr int HALO = (GEO == 0) ? 1 : 0;
-  constexpr int NPL = (GEO == 0) ? (BM == 256 ? 3 : 4) : (BM * 4 + NTHR - 1) / NTHR;  // patch pieces / thread
-  constexpr int NWP = TPS * BN * 4;         // weight 16-byte pieces per step
+  constexpr int TW = 1 << TWL, TH = BM >> TWL;
+  constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO;
+  constexpr int ROWP = (PW * PIXB + 255) & ~255;   // multiple of 256 B: two-row fragments stay conflict-free
+  constexpr int PB = PH * ROWP;
+  constexpr int WB = TPS * BN * PIXB;
+  constexpr int NP = PH * PW * 4;                  // patch 16-byte pieces per chunk
+  constexpr int NPL = (NP + NTHR - 1) / NTHR;
+  constexpr int NWP = TPS * BN * 4;                // weight 16-byte pieces per step
   constexpr int NWL = (NWP + NTHR - 1) / NTHR;
   static_assert(BM == 256 || BM == 128, "pixel tile is 256 or 128");
   static_assert(NTHR % 4 == 0, "a thread keeps one 16-byte slot of the 64-byte chunk");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   const int lr = lane & 31, lh = lane >> 5;
-
-  const int twl = a.twl, tw = 1 << twl, th = BM >> twl;
-  const int PW = tw + 2 * HALO, PH = th + 2 * HALO;
-  const int ROWP = (PW * PIXB + 255) & ~255;
-  const int PB = PH * ROWP;
-  constexpr int WB = TPS * BN * PIXB;
-
-  // ---- block -> (pixel tile, channel tile); XCD-contiguous so the N-tiles of a pixel tile share an L2
-  const int NT = a.Ntot / BN;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = lid / NT, nt = lid - mt * NT;
-  const int tpi = a.tiles_x * a.tiles_y;
-  const int b = mt / tpi;
-  const int trem = mt - b * tpi;
-  const int tyi = trem / a.tiles_x, txi = trem - tyi * a.tiles_x;
-  const int y0 = tyi * th, x0 = txi * tw;
-  const int n0 = nt * BN;
   const int H = a.H, W = a.W;
 
-  // ---- per-thread staging assignment (chunk-invariant)
+  // ---- work units
+  const int NT = a.Ntot / BN;
+  const int tpi = a.tiles_x * a.tiles_y;
+  const int U = a.B * tpi * NT;
+  int u, u_end, GW;
+  if (a.persistent) {
+    const int xcd = blockIdx.x & 7, upx = (U + 7) >> 3;
+    GW = gridDim.x >> 3;
+    u = xcd * upx + (blockIdx.x >> 3);
+    u_end = min(U, (xcd + 1) * upx);
+  } else {
+    u = xcd_remap(blockIdx.x, gridDim.x);
+    u_end = u + 1;
+    GW = 1;
+  }
+  if (u >= u_end) return;
+
+  // ---- unit-invariant staging assignment.  Straight-line staging: every thread always moves NPL patch
+  // pieces and NWL weight pieces; pieces past the tile's count read a valid dummy address and land in a
+  // per-thread trash slot behind the staging buffers, so there is no divergent control flow around
+  // loads or LDS stores.
+  constexpr int MAINB = PBUF * PB + 2 * WB;
+  const int trash = MAINB + tid * 16;
   const int pc = tid & 3;  // 16-byte slot inside the 64-byte chunk (NTHR % 4 == 0: same for every piece)
-  int ppix[NPL], plds[NPL];
-  {
-    const int NP = PH * PW * 4;
+  int plds[NPL], prel[NPL];   // LDS byte offset and packed patch-relative coordinates (py << 8 | px)
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const int q = tid + i * NTHR;
-      plds[i] = -1;
-      ppix[i] = -1;
-      if (q < NP) {
-        const int pix = q >> 2;
-        const int py = pix / PW, px = pix - py * PW;
-        const int gy = y0 + py - HALO, gx = x0 + px - HALO;
-        plds[i] = py * ROWP + px * PIXB + pc * 16;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-          ppix[i] = a.unshuf ? ((b * 2 * H + 2 * gy) * 2 * W + 2 * gx) : ((b * H + gy) * W + gx);
-      }
-    }
+  for (int i = 0; i < NPL; ++i) {
+    const int q = tid + i * NTHR;
+    const int pix = q >> 2;
+    const int py = pix / PW, px = pix - py * PW;
+    plds[i] = (q < NP) ? py * ROWP + px * PIXB + pc * 16 : trash;
+    prel[i] = (q < NP) ? ((py << 8) | px) : (0x7fff << 8);  // row 32767: outside every image, never valid
   }
   int wsrc[NWL], wlds[NWL];
 #pragma unroll
   for (int i = 0; i < NWL; ++i) {
     const int q = tid + i * NTHR;
-    wsrc[i] = -1;
-    wlds[i] = -1;
-    if (q < NWP) {
-      const int t = q / (BN * 4), r = q - t * (BN * 4);
-      wsrc[i] = t * a.Ntot * 64 + r * 16;            // byte offset from the step's weight base
-      wlds[i] = t * (BN * PIXB) + (r >> 2) * PIXB + (r & 3) * 16;
-    }
+    const int t = q / (BN * 4), r = q - t * (BN * 4);
+    wsrc[i] = (q < NWP) ? t * a.Ntot * 64 + r * 16 : 0;    // byte offset from the step's weight base
+    wlds[i] = (q < NWP) ? PBUF * PB + t * (BN * PIXB) + (r >> 2) * PIXB + (r & 3) * 16 : trash;
   }
-
   const int nchA = a.CA / E::CH;
   const int nchunks = a.unshuf ? 4 * nchA : (a.CA + a.CB) / E::CH;
   const int nsteps = nchunks * SPC;
-  const bool pro = (a.scale != nullptr);
 
-  uint4 preg[NPL], wreg[2][NWL];
+  // per-lane fragment addresses
+  int laneA[MF], laneB[NF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = (wm * MF + mf) * 32 + lr;
+    laneA[mf] = (m >> TWL) * ROWP + (m & (TW - 1)) * PIXB + lh * 16;
+  }
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) laneB[nf] = ((wn * NF + nf) * 32 + lr) * PIXB + lh * 16;
+
+  char* const patch0 = smem;
+  char* const wbuf0 = smem + PBUF * PB;
+
+  // ---- unit state
+  int ub, uy0, ux0, un0, umt;       // current unit
+  auto decode = [&](int uu, int& mt, int& b, int& y0, int& x0, int& n0) {
+    mt = uu / NT;
+    n0 = (uu - mt * NT) * BN;
+    b = mt / tpi;
+    const int trem = mt - b * tpi;
+    const int tyi = trem / a.tiles_x;
+    y0 = tyi * TH;
+    x0 = (trem - tyi * a.tiles_x) * TW;
+  };
+  u32x4 preg[NPL], wreg[NWL];
+  unsigned pvalid = 0;              // bit i: preg[i] holds an in-image pixel
   float psc[E::VEC], psh[E::VEC];
 
-  auto load_patch = [&](int kc) {
+  auto load_patch = [&](int kc, int b, int y0, int x0) {
     const T* src;
     int C, coff, tapadd = 0;
     if (a.unshuf) {
@@ -142,13 +182,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     } else {
       src = (const T*)a.srcB; C = a.CB; coff = (kc - nchA) * E::CH;
     }
+    const T* const base = src + coff + pc * E::VEC;
+    pvalid = 0;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);   // every element is always written: keeps preg[] in registers
-      if (ppix[i] >= 0) v = *(const uint4*)(src + ((size_t)(ppix[i] + tapadd) * C + coff + pc * E::VEC));
-      preg[i] = v;
+      const int gy = y0 + (prel[i] >> 8) - HALO, gx = x0 + (prel[i] & 255) - HALO;
+      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int cy = ok ? gy : y0, cx = ok ? gx : x0;      // clamp to the tile origin: always a valid pixel
+      const int lin = a.unshuf ? ((b * 2 * H + 2 * cy) * 2 * W + 2 * cx) : ((b * H + cy) * W + cx);
+      preg[i] = *(const u32x4*)(base + (size_t)(lin + tapadd) * C);
+      pvalid |= (ok ? 1u : 0u) << i;
     }
-    if (pro) {
+    if (PRO) {
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) {
         psc[j] = a.scale[coff + pc * E::VEC + j];
@@ -156,61 +201,47 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
       }
     }
   };
-  auto store_patch = [&](char* pbuf) {
+  auto store_patch = [&](int pboff) {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      if (plds[i] >= 0) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ppix[i] >= 0) {
-          v = preg[i];
-          if (pro) {  // BatchNorm(scale, shift) + ReLU of the producer layer, applied on load
-            float f[E::VEC];
-            unpack16<T>(v, f);
+      u32x4 v = preg[i];
+      if (PRO) {  // BatchNorm(scale, shift) + ReLU of the producer layer, applied on load
+        float f[E::VEC];
+        unpack16<T>(make_uint4(v.x, v.y, v.z, v.w), f);
 #pragma unroll
-            for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
-            v = pack16<T>(f);
-          }
-        }
-        *(uint4*)(pbuf + plds[i]) = v;
+        for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
+        const uint4 t = pack16<T>(f);
+        v = (u32x4){t.x, t.y, t.z, t.w};
       }
+      const bool ok = (pvalid >> i) & 1;   // out-of-image halo pixels are exact zeros (after the transform)
+      v = ok ? v : (u32x4){0u, 0u, 0u, 0u};
+      const int off = plds[i] + ((plds[i] < MAINB) ? pboff : 0);
+      *(u32x4*)(smem + off) = v;
     }
   };
-  auto load_w = [&](int s, uint4 (&wr)[NWL]) {
+  auto load_w = [&](int s, int n0) {
     const int kc = s / SPC, tg = s - kc * SPC;
     const char* wb = (const char*)a.w + ((size_t)(kc * NTAPS + tg * TPS) * a.Ntot + n0) * 64;
 #pragma unroll
+    for (int i = 0; i < NWL; ++i) wreg[i] = *(const u32x4*)(wb + wsrc[i]);
+  };
+  auto store_w = [&](int par) {
+#pragma unroll
     for (int i = 0; i < NWL; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (wsrc[i] >= 0) v = *(const uint4*)(wb + wsrc[i]);
-      wr[i] = v;
+      const int off = wlds[i] + ((wlds[i] < MAINB) ? par * WB : 0);
+      *(u32x4*)(smem + off) = wreg[i];
     }
   };
-  auto store_w = [&](char* wbuf, const uint4 (&wr)[NWL]) {
-#pragma unroll
-    for (int i = 0; i < NWL; ++i)
-      if (wlds[i] >= 0) *(uint4*)(wbuf + wlds[i]) = wr[i];
-  };
-
-  // ---- per-lane fragment addresses
-  int laneA[MF], laneB[NF];
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf) {
-    const int m = (wm * MF + mf) * 32 + lr;
-    laneA[mf] = (m >> twl) * ROWP + (m & (tw - 1)) * PIXB + lh * 16;
-  }
-#pragma unroll
-  for (int nf = 0; nf < NF; ++nf) laneB[nf] = ((wn * NF + nf) * 32 + lr) * PIXB + lh * 16;
 
   f32x16 acc[MF][NF];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
+      for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
-
-  char* const patch0 = smem;
-  char* const wbuf0 = smem + PBUF * PB;
+        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+  };
 
   // one tap (two MFMA k-steps over the 64-byte chunk) against LDS
   auto mma_tap = [&](const char* pb, const char* wb) {
@@ -228,184 +259,206 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     }
   };
 
-  if constexpr (GEO == 0) {
-    // Software pipeline, weights two steps ahead: at step s the registers of parity (s+1)&1 hold step s+1's
-    // weight tile (loaded during step s-1) and are written to LDS BETWEEN this step's MFMA groups, while
-    // the loads of step s+2 are issued into the other register set.  One barrier per step.
-    load_patch(0);
-    load_w(0, wreg[0]);
-    store_patch(patch0);
-    store_w(wbuf0, wreg[0]);
-    if (nsteps > 1) load_w(1, wreg[1]);
-    __syncthreads();
-
-    auto do_step = [&](auto TGc, auto PARc, int kc) {
-      constexpr int TG = decltype(TGc)::value, PAR = decltype(PARc)::value;
-      const int s = kc * 3 + TG;
-      const bool more_chunks = (kc + 1 < nchunks);
-      if (s + 2 < nsteps) load_w(s + 2, wreg[PAR]);
-      if (TG == 0 && more_chunks) load_patch(kc + 1);
-      const char* pb = patch0 + (PBUF == 2 ? (kc & 1) * PB : 0) + TG * ROWP;
-      const char* wb = wbuf0 + PAR * WB;
-      mma_tap(pb, wb);
-      if (s + 1 < nsteps) store_w(wbuf0 + (PAR ^ 1) * WB, wreg[PAR ^ 1]);
-      mma_tap(pb + PIXB, wb + BN * PIXB);
-      if (TG == 2 && PBUF == 2 && more_chunks) store_patch(patch0 + ((kc + 1) & 1) * PB);
-      mma_tap(pb + 2 * PIXB, wb + 2 * BN * PIXB);
-      __syncthreads();
-      if (TG == 2 && PBUF == 1 && more_chunks) {
-        store_patch(patch0);
-        __syncthreads();
-      }
-    };
-    int kc = 0;
-    for (; kc + 1 < nchunks; kc += 2) {   // six steps: register/LDS parities are compile-time constants
-      do_step(IC<0>{}, IC<0>{}, kc);
-      do_step(IC<1>{}, IC<1>{}, kc);
-      do_step(IC<2>{}, IC<0>{}, kc);
-      do_step(IC<0>{}, IC<1>{}, kc + 1);
-      do_step(IC<1>{}, IC<0>{}, kc + 1);
-      do_step(IC<2>{}, IC<1>{}, kc + 1);
-    }
-    if (kc < nchunks) {
-      do_step(IC<0>{}, IC<0>{}, kc);
-      do_step(IC<1>{}, IC<1>{}, kc);
-      do_step(IC<2>{}, IC<0>{}, kc);
-    }
-  } else {
-    // 1x1 geometry: one tap per chunk; patch + weights staged one step ahead
-    load_patch(0);
-    load_w(0, wreg[0]);
-    store_patch(patch0);
-    store_w(wbuf0, wreg[0]);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-      const bool has_next = (s + 1 < nsteps);
-      if (has_next) {
-        load_w(s + 1, wreg[0]);
-        load_patch(s + 1);
-      }
-      mma_tap(patch0 + (PBUF == 2 ? (s & 1) * PB : 0), wbuf0 + (s & 1) * WB);
-      if (PBUF == 1) __syncthreads();
-      if (has_next) {
-        store_w(wbuf0 + ((s + 1) & 1) * WB, wreg[0]);
-        store_patch(patch0 + (PBUF == 2 ? ((s + 1) & 1) * PB : 0));
-      }
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue: bias, BN statistics from fp32 accumulators, LDS transpose, coalesced store
+  // ---- epilogue (entered right after a barrier: nobody reads the staging LDS any more).
+  // FULL = the whole tile lies inside the image (the common case): no per-element bounds tests.
   constexpr int OP = BN * E::ES + 16;
-  char* const ot = smem;
-  float* const red = (float*)(smem + BM * OP);
-  const bool do_stats = (a.stats != nullptr);
-  float s1[NF], s2[NF];
-#pragma unroll
-  for (int nf = 0; nf < NF; ++nf) {
-    s1[nf] = 0.f;
-    s2[nf] = 0.f;
-    const int n = (wn * NF + nf) * 32 + lr;
-    const float bv = a.bias ? a.bias[n0 + n] : 0.f;
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (wm * MF + mf) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float v = acc[mf][nf][r] + bv;
-        const bool valid = (y0 + (m >> twl) < H) && (x0 + (m & (tw - 1)) < W);
-        if (valid) {
-          s1[nf] += v;
-          s2[nf] += v * v;
-        }
-        *(T*)(ot + m * OP + n * E::ES) = from_float<T>(v);
-      }
-    }
-  }
-  if (do_stats) {
+  auto epilogue_t = [&](auto FULLc) {
+    constexpr bool FULL = decltype(FULLc)::value;
+    char* const ot = smem;
+    float* const red = (float*)(smem + BM * OP);
+    const bool do_stats = (a.stats != nullptr);
+    float s1[NF], s2[NF];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
-      s1[nf] += __shfl_xor(s1[nf], 32);
-      s2[nf] += __shfl_xor(s2[nf], 32);
-      if (lh == 0) {
-        const int n = (wn * NF + nf) * 32 + lr;
-        red[(wm * BN + n) * 2 + 0] = s1[nf];
-        red[(wm * BN + n) * 2 + 1] = s2[nf];
+      s1[nf] = 0.f;
+      s2[nf] = 0.f;
+      const int n = (wn * NF + nf) * 32 + lr;
+      const float bv = a.bias ? a.bias[un0 + n] : 0.f;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int mb = (wm * MF + mf) * 32 + 4 * lh;
+        char* const obase = ot + mb * OP + n * E::ES;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = (r & 3) + 8 * (r >> 2);
+          const float v = acc[mf][nf][r] + bv;
+          float vs = v;
+          if (!FULL) {
+            const int m = mb + dm;
+            vs = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v : 0.f;
+          }
+          s1[nf] += vs;
+          s2[nf] = fmaf(vs, vs, s2[nf]);
+          *(T*)(obase + dm * OP) = from_float<T>(v);
+        }
       }
     }
-  }
-  __syncthreads();
-  if (do_stats && tid < BN) {
-    float t1 = 0.f, t2 = 0.f;
+    if (do_stats) {
 #pragma unroll
-    for (int w = 0; w < WM; ++w) {  // fixed order: bit-stable
-      t1 += red[(w * BN + tid) * 2 + 0];
-      t2 += red[(w * BN + tid) * 2 + 1];
+      for (int nf = 0; nf < NF; ++nf) {
+        s1[nf] += __shfl_xor(s1[nf], 32);
+        s2[nf] += __shfl_xor(s2[nf], 32);
+        if (lh == 0) {
+          const int n = (wn * NF + nf) * 32 + lr;
+          red[(wm * BN + n) * 2 + 0] = s1[nf];
+          red[(wm * BN + n) * 2 + 1] = s2[nf];
+        }
+      }
     }
-    float2* dst = (float2*)a.stats + (size_t)mt * a.Ntot + n0 + tid;
-    *dst = make_float2(t1, t2);
-  }
-  constexpr int CPR = BN * E::ES / 16;
-  for (int q = tid; q < BM * CPR; q += NTHR) {
-    const int m = q / CPR, cc = q - m * CPR;
-    const int ty = m >> twl, tx = m & (tw - 1);
-    if (y0 + ty >= H || x0 + tx >= W) continue;
-    const uint4 v = *(const uint4*)(ot + m * OP + cc * 16);
-    const int n = n0 + cc * E::VEC;
-    T* dst;
-    if (a.shuffle) {  // ConvTranspose2d(k=2,s=2): N = (a*2+c)*Cout + co -> pixel (2y+a, 2x+c)
-      const int tq = n0 / a.CO1, co = n - tq * a.CO1;
-      const size_t opix = ((size_t)(b * 2 * H + 2 * (y0 + ty) + (tq >> 1))) * (2 * W) + 2 * (x0 + tx) + (tq & 1);
-      dst = (T*)a.out + opix * a.CO1 + co;
+    __syncthreads();
+    if (do_stats && tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {  // fixed order: bit-stable
+        t1 += red[(w * BN + tid) * 2 + 0];
+        t2 += red[(w * BN + tid) * 2 + 1];
+      }
+      float2* dst = (float2*)a.stats + (size_t)umt * a.Ntot + un0 + tid;
+      *dst = make_float2(t1, t2);
+    }
+    constexpr int CPR = BN * E::ES / 16;   // 16-byte chunks per pixel row of the tile
+    constexpr int NST = BM * CPR / NTHR;
+    static_assert(BM * CPR % NTHR == 0 && (CPR & (CPR - 1)) == 0, "store loop is exact");
+    const int cc = tid & (CPR - 1);
+    const int n = un0 + cc * E::VEC;
+    // destination of this thread's channel slice at the tile origin, and the per-pixel element stride
+    T* dbase;
+    size_t pstride, rstride;       // elements per pixel step in x / per row step in y
+    if (a.shuffle) {               // ConvTranspose2d(k=2,s=2): N = (a*2+c)*Cout + co -> pixel (2y+a, 2x+c)
+      const int tq = un0 / a.CO1, co = n - tq * a.CO1;
+      dbase = (T*)a.out + (((size_t)(ub * 2 * H + 2 * uy0 + (tq >> 1))) * (2 * W) + 2 * ux0 + (tq & 1)) * a.CO1 + co;
+      pstride = 2 * (size_t)a.CO1;
+      rstride = 4 * (size_t)W * a.CO1;
     } else {
-      const size_t pix = ((size_t)(b * H + y0 + ty)) * W + x0 + tx;
-      if (n < a.CO1) dst = (T*)a.out + pix * a.CO1 + n;
-      else dst = (T*)a.out2 + pix * a.CO2 + (n - a.CO1);
+      const size_t pix0 = ((size_t)(ub * H + uy0)) * W + ux0;
+      if (n < a.CO1) { dbase = (T*)a.out + pix0 * a.CO1 + n; pstride = a.CO1; }
+      else { dbase = (T*)a.out2 + pix0 * a.CO2 + (n - a.CO1); pstride = a.CO2; }
+      rstride = (size_t)W * pstride;
     }
-    *(uint4*)dst = v;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int m = (tid + i * NTHR) / CPR;
+      const int ty = m >> TWL, tx = m & (TW - 1);
+      const uint4 v = *(const uint4*)(ot + m * OP + cc * 16);
+      if (FULL || (uy0 + ty < H && ux0 + tx < W)) *(uint4*)(dbase + ty * rstride + tx * pstride) = v;
+    }
+  };
+  auto epilogue = [&]() {
+    if ((uy0 + TH <= H) && (ux0 + TW <= W)) epilogue_t(std::true_type{});
+    else epilogue_t(std::false_type{});
+  };
+
+  // ---- first unit: stage chunk 0 / step 0
+  decode(u, umt, ub, uy0, ux0, un0);
+  zero_acc();
+  load_patch(0, ub, uy0, ux0);
+  load_w(0, un0);
+  store_patch(0);
+  store_w(0);
+  __syncthreads();
+
+  for (;;) {
+    const int un = u + GW;
+    const bool has_next = un < u_end;
+    int nmt = 0, nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
+    if (has_next) decode(un, nmt, nb, ny0, nx0, nn0);
+
+    int kc = 0, tg = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const bool last_step = (s + 1 == nsteps);
+      const bool more_chunks = (kc + 1 < nchunks);
+      // issue-early: next weight step (wrapping into the next unit) and, at a chunk's first step, the next
+      // patch chunk (the next unit's chunk 0 during the last chunk)
+      if (!last_step) load_w(s + 1, un0);
+      else if (has_next) load_w(0, nn0);
+      if (tg == 0) {
+        if (more_chunks) load_patch(kc + 1, ub, uy0, ux0);
+        else if (has_next) load_patch(0, nb, ny0, nx0);
+      }
+      const char* pb = patch0 + (PBUF == 2 ? (kc & 1) * PB : 0) + (GEO == 0 ? tg * ROWP : 0);
+      const char* wb = wbuf0 + (s & 1) * WB;
+#pragma unroll
+      for (int t = 0; t < TPS; ++t) mma_tap(pb + t * PIXB, wb + t * (BN * PIXB));
+      // write-late: the data issued above (or a step / chunk earlier) lands in the other LDS buffers
+      if (!last_step) store_w((s + 1) & 1);
+      if (tg == SPC - 1 && more_chunks && PBUF == 2) store_patch(((kc + 1) & 1) * PB);
+      __syncthreads();
+      if (tg == SPC - 1 && more_chunks && PBUF == 1) {
+        store_patch(0);
+        __syncthreads();
+      }
+      if (++tg == SPC) { tg = 0; ++kc; }
+    }
+    epilogue();
+    if (!has_next) break;
+    __syncthreads();                 // the epilogue's LDS reads are done: staging LDS may be rewritten
+    store_w(0);                      // next unit's step 0 (buffer parity restarts at 0)
+    store_patch(0);                  // next unit's chunk 0
+    zero_acc();
+    u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
+    __syncthreads();
   }
 }
 
-template <typename T, int GEO, int WM, int WN, int MF, int NF, int PBUF>
-int launch_cfg(ConvArgs a, hipStream_t st) {
+template <typename T, int GEO, int TWL, int WM, int WN, int MF, int NF, int PBUF, bool PRO>
+int launch_pro(ConvArgs a, hipStream_t st) {
   using E = ET<T>;
   constexpr int BM = WM * MF * 32, BN = WN * NF * 32, NTHR = WM * WN * 64;
   constexpr int HALO = (GEO == 0) ? 1 : 0;
   constexpr int TPS = (GEO == 0) ? 3 : 1;
-  a.twl = segk_conv_twl(BM, a.W);
-  const int tw = 1 << a.twl, th = BM >> a.twl;
-  a.tiles_x = cdiv(a.W, tw);
-  a.tiles_y = cdiv(a.H, th);
-  const int PW = tw + 2 * HALO, PH = th + 2 * HALO;
-  const int ROWP = (PW * PIXB + 255) & ~255;
-  const size_t main_b = PBUF * (size_t)PH * ROWP + 2 * (size_t)TPS * BN * PIXB;
-  const size_t epi_b = BM * (size_t)(BN * E::ES + 16) + (size_t)WM * BN * 8;
-  const size_t lds = main_b > epi_b ? main_b : epi_b;
-  SEGK_REQUIRE(lds <= 160 * 1024, "conv_igemm: LDS %zu exceeds 160 KiB", lds);
-  const int grid = a.B * a.tiles_x * a.tiles_y * (a.Ntot / BN);
-  auto kern = conv_igemm_kernel<T, GEO, WM, WN, MF, NF, PBUF>;
+  constexpr int TW = 1 << TWL, TH = BM >> TWL;
+  constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO;
+  constexpr int ROWP = (PW * PIXB + 255) & ~255;
+  a.twl = TWL;
+  a.tiles_x = cdiv(a.W, TW);
+  a.tiles_y = cdiv(a.H, TH);
+  constexpr size_t main_b = PBUF * (size_t)PH * ROWP + 2 * (size_t)TPS * BN * PIXB + NTHR * 16;   // + trash slots
+  constexpr size_t epi_b = BM * (size_t)(BN * E::ES + 16) + (size_t)WM * BN * 8;
+  constexpr size_t lds = main_b > epi_b ? main_b : epi_b;
+  static_assert(lds <= 160 * 1024, "conv_igemm: LDS exceeds 160 KiB");
+  const int units = a.B * a.tiles_x * a.tiles_y * (a.Ntot / BN);
+  const int per_xcd = (units + 7) / 8;
+  // persistent grid: as many workgroups per CU as LDS allows (the register budget allows 2 x 8 waves)
+  int wg_per_cu = (int)((160 * 1024) / lds);
+  const int wg_cap = (NTHR == 512) ? 1 : 2;
+  if (wg_per_cu > wg_cap) wg_per_cu = wg_cap;
+  int gw = (num_cus() / 8) * wg_per_cu;
+  if (gw > per_xcd) gw = per_xcd;
+  a.persistent = 1;
+  auto kern = conv_igemm_kernel<T, GEO, TWL, WM, WN, MF, NF, PBUF, PRO>;
   static bool attr_set = false;  // idempotent; racing setters write the same value
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SEGK_FAIL(-3, "conv_igemm: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(8 * gw), dim3(NTHR), lds, st, a);
   SEGK_CHECK_LAUNCH("conv_igemm");
   return 0;
+}
+
+template <typename T, int GEO, int TWL, int WM, int WN, int MF, int NF, int PBUF>
+int launch_cfg(const ConvArgs& a, hipStream_t st) {
+  if constexpr (GEO == 0) {
+    if (a.scale) return launch_pro<T, GEO, TWL, WM, WN, MF, NF, PBUF, true>(a, st);
+  }
+  return launch_pro<T, GEO, TWL, WM, WN, MF, NF, PBUF, false>(a, st);
 }
 
 template <typename T, int GEO>
 int launch_geo(const ConvArgs& a, hipStream_t st) {
   // BN must divide N; with the pixel-shuffle store a channel tile must not straddle two taps.
   const int unit = a.shuffle ? a.CO1 : a.Ntot;
-  if (unit % 128 == 0) return launch_cfg<T, GEO, 4, 2, 2, 2, 2>(a, st);            // 256 px x 128 ch, 8 waves
+  const bool wide = a.W > 16;                      // 8x32 tiles unless the image is at most 16 wide
+  if (unit % 128 == 0)                             // 256 px x 128 ch, 8 waves
+    return wide ? launch_cfg<T, GEO, 5, 4, 2, 2, 2, 2>(a, st) : launch_cfg<T, GEO, 4, 4, 2, 2, 2, 2>(a, st);
   if constexpr (GEO == 0) {
-    if (unit % 64 == 0) return launch_cfg<T, GEO, 2, 2, 2, 1, 1>(a, st);           // 128 px x 64 ch, 4 waves
-    return launch_cfg<T, GEO, 4, 1, 1, 1, 1>(a, st);                               // 128 px x 32 ch, 4 waves
+    if (unit % 64 == 0) return launch_cfg<T, GEO, 4, 2, 2, 2, 1, 1>(a, st);        // 128 px x 64 ch, 4 waves
+    return launch_cfg<T, GEO, 4, 4, 1, 1, 1, 1>(a, st);                            // 128 px x 32 ch, 4 waves
   } else {
-    if (unit % 64 == 0) return launch_cfg<T, GEO, 4, 2, 2, 1, 2>(a, st);
-    return launch_cfg<T, GEO, 8, 1, 1, 1, 2>(a, st);
+    if (unit % 64 == 0)
+      return wide ? launch_cfg<T, GEO, 5, 4, 2, 2, 1, 2>(a, st) : launch_cfg<T, GEO, 4, 4, 2, 2, 1, 2>(a, st);
+    return wide ? launch_cfg<T, GEO, 5, 8, 1, 1, 1, 2>(a, st) : launch_cfg<T, GEO, 4, 8, 1, 1, 1, 2>(a, st);
   }
 }
 
@@ -422,7 +475,7 @@ int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st
   SEGK_REQUIRE(a.CA > 0 && a.CA % CH == 0, "conv_igemm: CA=%d must be a positive multiple of %d", a.CA, CH);
   SEGK_REQUIRE(a.CB >= 0 && a.CB % CH == 0 && (a.CB == 0) == (a.srcB == nullptr), "conv_igemm: bad second source");
   SEGK_REQUIRE(!(a.unshuf && (a.CB || geo != 1)), "conv_igemm: un-shuffle gather needs geo 1, single source");
-  SEGK_REQUIRE(!(a.scale && a.CB), "conv_igemm: BN prologue with two sources is unsupported");
+  SEGK_REQUIRE(!(a.scale && (a.CB || geo != 0)), "conv_igemm: BN prologue needs the 3x3 geometry and one source");
   SEGK_REQUIRE((a.scale == nullptr) == (a.shift == nullptr), "conv_igemm: scale/shift must come together");
   SEGK_REQUIRE(a.Ntot > 0 && a.Ntot % 32 == 0, "conv_igemm: N=%d must be a multiple of 32", a.Ntot);
   SEGK_REQUIRE(a.CO1 > 0 && a.CO1 % 32 == 0 && a.CO2 >= 0 && a.CO2 % 32 == 0, "conv_igemm: bad output channels");

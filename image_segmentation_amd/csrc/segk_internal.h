@@ -18,6 +18,7 @@ struct ConvArgs {
   int Ntot, CO1, CO2;
   int twl, tiles_x, tiles_y;
   int unshuf, shuffle;
+  int persistent;       // set by the launcher
 };
 int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st);
 int segk_conv_bm(int geo, int unit);      // pixels per tile for a layer with N = unit output channels
