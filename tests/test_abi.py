@@ -1,0 +1,65 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/segk.h declares; the ctypes table
+(image_segmentation_amd/_lib.py) mirrors the header one to one (same names, same argument counts).
+No compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_protos():
+    txt = open(os.path.join(ROOT, "include", "segk.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(segk_\w+)\s*\(([^)]*)\)\s*;", txt):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",")])
+        protos[m.group(1)] = n
+    return protos
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from image_segmentation_amd import build, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    return _lib
+
+
+def test_header_is_nonempty():
+    p = header_protos()
+    assert len(p) >= 25 and "segk_conv3x3" in p and "segk_wgrad" in p and "segk_loss_fwd" in p
+
+
+def test_library_exports_every_declared_symbol(lib):
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for name in header_protos():
+        assert hasattr(so, name), f"{name} declared in include/segk.h but not exported by libsegk.so"
+
+
+def test_ctypes_table_matches_header(lib):
+    protos = header_protos()
+    assert set(protos) == set(lib.SIGNATURES), set(protos) ^ set(lib.SIGNATURES)
+    for name, nargs in protos.items():
+        assert len(lib.SIGNATURES[name][1]) == nargs, name
+
+
+def test_load_and_version(lib):
+    so = lib.load()
+    assert so.segk_version() >= 100
+    assert so.segk_last_error() is not None
+    # pure size queries work without a GPU
+    assert lib.query("segk_conv_tiles", 2, 32, 32, 64) == 2 * 4 * 2          # 8x16 tiles for a 64-channel layer
+    assert lib.query("segk_conv_tiles", 2, 32, 32, 128) == 2 * 4 * 1         # 8x32 tiles for 128 channels
+    assert lib.query("segk_bn_stats_floats", 4, 64) == 4 * 64 * 2 + 32 * 64 * 4
+    assert lib.query("segk_loss_state_floats") >= 4 + 3 * 8
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libsegk.so")
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        lib.load()

@@ -1,0 +1,139 @@
+"""CPU: host-side logic of the drop-in surface -- train_loop / eval_loop protocol (reference
+utils/training.py:18-121) driven with the CPU oracle model, MetricsHistory formulas, loss-module argument
+contracts, state_dict layout, act-tensor bookkeeping and the guarantee that the product path refuses CPU
+tensors instead of silently falling back."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.fill import fill, labels, fill_module
+from oracle import unet_ref, losses_ref
+import image_segmentation_amd as seg
+from image_segmentation_amd import training, ops
+from image_segmentation_amd.metrics import MetricsHistory
+
+training.VERBOSE = False
+
+
+class OracleCE(torch.nn.Module):
+    def forward(self, pred, y):
+        return losses_ref.cross_entropy(pred, y)
+
+
+def test_train_loop_matches_reference_protocol(golden):
+    """same data / model / AdamW as tools/gen_golden.py:gen_trainloop, run through OUR train_loop"""
+    g = golden("trainloop_unet_32")
+    for acc in (1, 2):
+        m = unet_ref.unet(3, 3); fill_module(m, 1000)
+        opt = torch.optim.AdamW(m.parameters(), weight_decay=0.01)
+        data = [(fill((2, 3, 32, 32), 10 + i, 0, 1), labels((2, 1, 32, 32), 20 + i, 3)) for i in range(3)]
+        avg = training.train_loop(data, m, OracleCE(), opt, acc, torch.device("cpu"))
+        assert abs(avg - float(g[f"acc{acc}_avg"])) < 1e-5
+        np.testing.assert_allclose(m.output.weight.detach().numpy(), g[f"acc{acc}_out_w"], atol=2e-5)
+        np.testing.assert_allclose(m.down1.doubleConvReLU[1].running_mean.numpy(), g[f"acc{acc}_rm"], atol=1e-6)
+
+
+def test_train_loop_scheduler_and_accumulation_order():
+    calls = []
+
+    class Opt:
+        param_groups = [{"lr": 0.1}]
+        def zero_grad(self): calls.append("zero")
+        def step(self): calls.append("step")
+
+    class Sched:
+        def step(self): calls.append("sched")
+
+    class GS:
+        def arm(self): calls.append("arm")
+        def sync(self): calls.append("sync")
+
+    w = torch.nn.Parameter(torch.ones(1))
+    model = torch.nn.Module(); model.forward = lambda X: X * w
+    data = [(torch.ones(1, 1), torch.zeros(1, 1, dtype=torch.long)) for _ in range(3)]
+    loss_fn = lambda p, y: (p.sum() - 3.0) ** 2
+    avg = training.train_loop(data, model, loss_fn, Opt(), 2, "cpu", scheduler=Sched(), grad_sync=GS())
+    # zero first; step after micro-batch 2 and after the last (3rd) batch; scheduler right after optimizer
+    assert calls == ["zero", "arm", "sync", "step", "sched", "zero", "arm", "sync", "step", "sched", "zero"]
+    assert avg == pytest.approx(4.0)
+
+
+class OracleAgg(MetricsHistory):
+    """CPU stand-in for the device confusion kernel (host formulas unchanged)."""
+    def accumulate(self, pred, label):
+        c = losses_ref.confusion_counts(pred, label, self.num_classes)
+        self.total_tp += c[0]; self.total_fp += c[1]; self.total_fn += c[2]; self.total_tn += c[3]
+
+
+def test_eval_loop_and_metrics_known_answers(golden):
+    g = golden("unet_3_3_b4_128")
+    logits = torch.from_numpy(g["logits"])
+    Y = labels((4, 1, 128, 128), 2, 3)
+
+    class Fixed(torch.nn.Module):       # a "model" that returns the golden logits for each batch of one image
+        def __init__(self): super().__init__(); self.i = 0
+        def forward(self, X):
+            out = logits[self.i:self.i + X.shape[0]]; self.i += X.shape[0]; return out
+    data = [([fill((3, 128, 128), 50 + i, 0, 1)], [Y[i, 0]]) for i in range(4)]
+    agg = OracleAgg(3)
+    loss, dice, iou = training.eval_loop(data, Fixed(), OracleCE(), "cpu", 128, agg)
+    counts = np.stack([agg.total_tp.numpy(), agg.total_fp.numpy(), agg.total_fn.numpy(), agg.total_tn.numpy()])
+    assert (counts == g["counts"]).all()
+    np.testing.assert_allclose([dice, iou], g["metrics"][:2], rtol=1e-12)
+    assert abs(loss - float(g["ce"])) < 1e-4        # mean of per-image CE == batch CE (equal image sizes)
+    assert len(agg.get_mean_iou_history()) == 1 and agg.get_last_per_class_iou().shape == (3,)
+
+
+def test_metrics_from_confusion_matrix(golden):
+    g = golden("unet_3_3_b4_128")
+    hard = g["argmax"].astype(np.int64); lab = labels((4, 128, 128), 2, 3).numpy()
+    M = np.zeros((3, 3), dtype=np.int64)
+    for p in range(3):
+        for l in range(3):
+            M[p, l] = ((hard == p) & (lab == l)).sum()
+    tp, fp, fn, tn = MetricsHistory.counts_from_confusion(torch.from_numpy(M), hard.size)
+    assert (np.stack([tp, fp, fn, tn]) == g["counts"]).all()
+    agg = MetricsHistory(4, ignore_index=3)
+    assert agg.mask.tolist() == [True, True, True, False] and agg.get_ignore_index() == 3
+
+
+def test_state_dict_layout_matches_reference_names():
+    a, b = seg.unet(3, 4), unet_ref.unet(3, 4)
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    assert "down1.doubleConvReLU.0.weight" in a.state_dict()
+    assert "down2.maxpool_doubleConv.1.doubleConvReLU.4.num_batches_tracked" in a.state_dict()
+    assert a.state_dict()["up1.upsample.weight"].shape == (1024, 512, 2, 2)
+    torch.manual_seed(0); x = seg.unet(3, 3)
+    torch.manual_seed(0); y = unet_ref.unet(3, 3)
+    assert all(torch.equal(p, q) for p, q in zip(x.parameters(), y.parameters()))   # same default init stream
+
+
+def test_product_path_refuses_cpu_tensors():
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        seg.unet(3, 3)(torch.zeros(1, 3, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        seg.CrossEntropyLoss()(torch.zeros(1, 3, 4, 4), torch.zeros(1, 4, 4, dtype=torch.long))
+
+
+def test_loss_argument_contracts():
+    x = torch.zeros(2, 3, 4, 4)
+    with pytest.raises(ValueError):      # bare Dice rejects [N,H,W] like the reference (weighted_loss.py:42-46)
+        seg.WeightedMemoryEfficientDiceLoss()(x, torch.zeros(2, 4, 4, dtype=torch.long))
+    with pytest.raises(ValueError):      # multi-channel targets (weighted_loss.py:146-150)
+        seg.WeightedDiceCELoss()(x, torch.zeros(2, 3, 4, 4, dtype=torch.long))
+    with pytest.raises(ValueError):
+        seg.WeightedDiceCELoss()(x, torch.zeros(2, 4, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        seg.CrossEntropyLoss(reduction="sum")
+
+
+def test_act_tensor_bookkeeping():
+    assert ops.pad32(3) == 32 and ops.pad32(64) == 64 and ops.pad32(65) == 96
+    buf = torch.zeros(2, 5, 7, 32)
+    v = ops.act_view(buf, 3)
+    assert v.shape == (2, 3, 5, 7) and v.stride() == (5 * 7 * 32, 1, 7 * 32, 32)
+    assert ops.act_info(v, torch.float32) is None            # CPU tensors never qualify
+    ops.set_compute_dtype(torch.float32); assert ops.get_compute_dtype() == torch.float32
+    ops.set_compute_dtype(torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.set_compute_dtype(torch.float16)
