@@ -4,3 +4,4 @@ utils/training.py loops).  Requires the in-tree HIP library (python -m image_seg
 from .ops import set_compute_dtype, get_compute_dtype      # noqa: F401
 from .unet import unet, DoubleConvReLU, Down, Up             # noqa: F401
 from .losses import CrossEntropyLoss, WeightedMemoryEfficientDiceLoss, WeightedDiceCELoss   # noqa: F401
+from .clipunet import ClipUNet, UNetDecoder, DecoderBlock, ClipViTEncoder                   # noqa: F401

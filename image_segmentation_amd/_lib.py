@@ -38,6 +38,8 @@ SIGNATURES = {
     "segk_channel_sum": (_i, [_vp, _l, _i, _i, _fp, _fp, _i, _vp]),
     "segk_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "segk_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_head_fwd": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_head_part_floats": (_i, [_l, _i]),
     "segk_head_bwd": (_i, [_fp, _vp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -85,6 +85,9 @@ def to_act(x, dtype):
         return x
     B, C, H, W = x.shape
     src = x.detach()
+    if C % 32 == 0 and src.stride(1) == 1 and src.permute(0, 2, 3, 1).is_contiguous():
+        # already dense NHWC (e.g. ViT token grids), only the dtype differs: cast in place of a re-layout
+        return act_view(src.permute(0, 2, 3, 1).to(dtype), C)
     if src.dtype != torch.float32 or not src.is_contiguous():
         src = src.float().contiguous()       # layout/dtype normalisation of a foreign tensor (edge only)
     out = torch.empty((B, H, W, pad32(C)), dtype=dtype, device=x.device)
@@ -517,6 +520,31 @@ class Conv1x1Fn(torch.autograd.Function):
         dw = wgrad_to_param(slabs, S, w.shape, Cout, Cin, 0, 1, dev)
         db = channel_sum(pd, B * H * W, Cout, dtype, dev) if ctx.has_bias else None
         return None, dx, dw, db
+
+
+class BilinearFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) -- reference clip/clipunet.py:99-100."""
+
+    @staticmethod
+    def forward(ctx, x, size, dtype):
+        _require_cuda(x, "bilinear resize")
+        x_t, px, Cp = _raw(x, dtype)
+        B, C, IH, IW = x.shape
+        OH, OW = int(size[0]), int(size[1])
+        y = torch.empty((B, OH, OW, Cp), dtype=dtype, device=x.device)
+        with _span("bilinear_fwd", 0.0, B * (IH * IW + OH * OW) * C * _es(dtype)):
+            _lib.call("segk_bilinear_fwd", px, y.data_ptr(), B, IH, IW, OH, OW, Cp, _DT[dtype], _stream())
+        ctx.cfg = (B, C, IH, IW, OH, OW, Cp, dtype)
+        return act_view(y, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, IH, IW, OH, OW, Cp, dtype = ctx.cfg
+        d_t, pd, _ = _raw(dy, dtype)
+        dx = torch.empty((B, IH, IW, Cp), dtype=dtype, device=dy.device)
+        with _span("bilinear_bwd", 0.0, B * (IH * IW + OH * OW) * C * _es(dtype)):
+            _lib.call("segk_bilinear_bwd", pd, dx.data_ptr(), B, IH, IW, OH, OW, Cp, _DT[dtype], _stream())
+        return act_view(dx, C), None, None
 
 
 class HeadFn(torch.autograd.Function):

@@ -111,6 +111,13 @@ int segk_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int Cp, int
 int segk_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate,
                         int dtype, segk_stream_t s);
 
+/* ---- bilinear resize, align_corners=False (clip/clipunet.py:99-100: skip features 14x14 -> decoder grid) ----
+ * x [B,IH,IW,Cp] -> y [B,OH,OW,Cp]; backward is a deterministic gather dy -> dx */
+int segk_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,
+                      segk_stream_t s);
+int segk_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,
+                      segk_stream_t s);
+
 /* ---- output head: Conv2d(C, ncls, 1) (unet.py:91,105; clipunet.py:181,187) ----------------------- */
 /* y NHWC [B,H,W,Cp] -> logits NCHW fp32 [B,ncls,H,W];  w fp32 [ncls][C], bias [ncls] */
 int segk_head_fwd(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp,
