@@ -50,8 +50,9 @@ int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cin
   return segk_pack_convt_weight_impl(w, dst, Cin, Cout, Cinp, Coutp, mode, dtype, (hipStream_t)s);
 }
 
-int segk_conv_tiles(int B, int H, int W, int Cout) {
-  const int bm = segk_conv_bm(0, Cout), twl = segk_conv_twl(bm, W);
+int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype) {
+  const int bm = segk_conv_use_ws(Cin, Cout, dtype) ? 256 : segk_conv_bm(0, Cout);
+  const int twl = segk_conv_twl(bm, W);
   return B * cdiv(W, 1 << twl) * cdiv(H, bm >> twl);
 }
 

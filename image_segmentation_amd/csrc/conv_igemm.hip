@@ -29,6 +29,11 @@
 #include "segk_internal.h"
 
 // pixel-tile geometry shared by the launcher and the BN-statistics sizing query (api.hip)
+// weight-stationary kernel: at most two 64-byte input chunks and N a multiple of 64 (but not a 128-wide layer
+// with a long K, which the MFMA-bound streaming kernel serves better)
+int segk_conv_use_ws(int cin_p, int n_p, int dtype) {
+  return dtype == SEGK_DT_BF16 && cin_p <= 64 && n_p % 64 == 0;   // bf16 performance mode only
+}
 int segk_conv_bm(int geo, int unit) { return (unit % 128 == 0 || geo != 0) ? 256 : 128; }
 int segk_conv_twl(int bm, int W) { return bm == 128 ? 4 : (W > 16 ? 5 : 4); }   // 8x16 | 8x32 | 16x16 tiles
 
@@ -400,6 +405,275 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight-stationary variant for the narrow, high-resolution layers (Cin <= 2 chunks, 64 output channels per
+// tile: the 3->64 stem, the 64->64 convs of down1/up4 and the 64->128 concat gradient): these are HBM-bound
+// (K = 9*Cin is tiny), so the structure is built around keeping the memory pipes busy instead of the
+// matrix cores.  All 9*Cin*64 weights of the workgroup's channel tile are loaded into LDS ONCE; a
+// persistent workgroup (8 waves, 256-pixel tiles) then streams pixel tiles: the next tile's patch is
+// fetched into registers before the current tile's barrier-free MFMA loop (36 k-steps), so its HBM
+// latency hides under the matrix work, and the only barriers left are the four around the epilogue.
+template <typename T, int TWL, bool PRO>
+__global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvArgs a) {
+  using E = ET<T>;
+  constexpr int WM = 4, WN = 2, MF = 2, NF = 1, NTHR = 512, BM = 256, BN = 64, MAXCH = 2;
+  constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
+  constexpr int ROWP = (PW * PIXB + 255) & ~255;
+  constexpr int PB = PH * ROWP;                    // one chunk of the patch
+  constexpr int WTAP = BN * PIXB;                  // one tap of one chunk of the weights
+  constexpr int NP = PH * PW * 4, NPL = (NP + NTHR - 1) / NTHR;
+  constexpr int WOFF = MAXCH * PB;                 // weights live behind the patch chunks
+  constexpr int MAINB = WOFF + MAXCH * 9 * WTAP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int H = a.H, W = a.W;
+  const int nchunks = (a.CA + a.CB) / E::CH;       // 1 or 2 (checked by the launcher)
+  const int nchA = a.CA / E::CH;
+
+  // units: the channel tile is fixed per workgroup (its weights stay resident); pixel tiles are walked
+  // with stride GW inside the XCD's contiguous range
+  const int NT = a.Ntot / BN;
+  const int tpi = a.tiles_x * a.tiles_y, MT = a.B * tpi;
+  const int xcd = blockIdx.x & 7, wgi = blockIdx.x >> 3, GWX = gridDim.x >> 3;
+  const int nt = wgi % NT, GW = GWX / NT;
+  const int mpx = (MT + 7) >> 3;
+  int mt = xcd * mpx + wgi / NT;
+  const int mt_end = min(MT, (xcd + 1) * mpx);
+  if (mt >= mt_end) return;
+  const int n0 = nt * BN;
+
+  const int trash = MAINB + tid * 16;
+  const int pc = tid & 3;
+  int plds[NPL], prel[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int q = tid + i * NTHR;
+    const int pix = q >> 2;
+    const int py = pix / PW, px = pix - py * PW;
+    plds[i] = (q < NP) ? py * ROWP + px * PIXB + pc * 16 : trash;
+    prel[i] = (q < NP) ? ((py << 8) | px) : (0x7fff << 8);
+  }
+  int laneA[MF], laneB;
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = (wm * MF + mf) * 32 + lr;
+    laneA[mf] = (m >> TWL) * ROWP + (m & (TW - 1)) * PIXB + lh * 16;
+  }
+  laneB = WOFF + (wn * 32 + lr) * PIXB + lh * 16;
+
+  // ---- resident weights: [chunk][tap][64 rows][80 B]
+  {
+    const int total = nchunks * 9 * BN * 4;
+    for (int q = tid; q < total; q += NTHR) {
+      const int r = q & (BN * 4 - 1), ct = q / (BN * 4);     // ct = chunk*9 + tap
+      const u32x4 v = *(const u32x4*)((const char*)a.w + ((size_t)ct * a.Ntot + n0) * 64 + r * 16);
+      *(u32x4*)(smem + WOFF + ct * WTAP + (r >> 2) * PIXB + (r & 3) * 16) = v;
+    }
+  }
+
+  u32x4 preg[MAXCH][NPL];
+  unsigned pvalid = 0;
+  float psc[MAXCH][E::VEC], psh[MAXCH][E::VEC];
+  if (PRO) {
+#pragma unroll
+    for (int kc = 0; kc < MAXCH; ++kc)
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) {
+        const int c = (kc < nchunks ? kc : 0) * E::CH + pc * E::VEC + j;
+        psc[kc][j] = a.scale[c];
+        psh[kc][j] = a.shift[c];
+      }
+  }
+  auto load_patch = [&](int b, int y0, int x0) {
+    pvalid = 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int gy = y0 + (prel[i] >> 8) - 1, gx = x0 + (prel[i] & 255) - 1;
+      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int cy = ok ? gy : y0, cx = ok ? gx : x0;
+      const size_t lin = (size_t)(b * H + cy) * W + cx;
+      pvalid |= (ok ? 1u : 0u) << i;
+#pragma unroll
+      for (int kc = 0; kc < MAXCH; ++kc) {
+        const int k = kc < nchunks ? kc : 0;                  // unused second chunk: harmless duplicate load
+        const T* src = (k < nchA) ? (const T*)a.srcA + lin * a.CA + k * E::CH
+                                  : (const T*)a.srcB + lin * a.CB + (k - nchA) * E::CH;
+        preg[kc][i] = *(const u32x4*)(src + pc * E::VEC);
+      }
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int kc = 0; kc < MAXCH; ++kc)
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        u32x4 v = preg[kc][i];
+        if (PRO) {
+          float f[E::VEC];
+          unpack16<T>(make_uint4(v.x, v.y, v.z, v.w), f);
+#pragma unroll
+          for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], psc[kc][j], psh[kc][j]), 0.f);
+          const uint4 t = pack16<T>(f);
+          v = (u32x4){t.x, t.y, t.z, t.w};
+        }
+        const bool ok = (pvalid >> i) & 1;
+        v = ok ? v : (u32x4){0u, 0u, 0u, 0u};
+        const int off = plds[i] + ((plds[i] < MAINB) ? kc * PB : 0);
+        *(u32x4*)(smem + off) = v;
+      }
+  };
+
+  f32x16 acc[MF];
+  int ub, uy0, ux0;
+  auto decode = [&](int m, int& b, int& y0, int& x0) {
+    b = m / tpi;
+    const int trem = m - b * tpi;
+    const int tyi = trem / a.tiles_x;
+    y0 = tyi * TH;
+    x0 = (trem - tyi * a.tiles_x) * TW;
+  };
+
+  constexpr int OP = BN * E::ES + 16;
+  auto epilogue_t = [&](auto FULLc) {
+    constexpr bool FULL = decltype(FULLc)::value;
+    char* const ot = smem;
+    float* const red = (float*)(smem + BM * OP);
+    const bool do_stats = (a.stats != nullptr);
+    float s1 = 0.f, s2 = 0.f;
+    const int n = wn * 32 + lr;
+    const float bv = a.bias ? a.bias[n0 + n] : 0.f;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int mb = (wm * MF + mf) * 32 + 4 * lh;
+      char* const obase = ot + mb * OP + n * E::ES;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2);
+        const float v = acc[mf][r] + bv;
+        float vs = v;
+        if (!FULL) {
+          const int m = mb + dm;
+          vs = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v : 0.f;
+        }
+        s1 += vs;
+        s2 = fmaf(vs, vs, s2);
+        *(T*)(obase + dm * OP) = from_float<T>(v);
+      }
+    }
+    if (do_stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lh == 0) {
+        red[(wm * BN + n) * 2 + 0] = s1;
+        red[(wm * BN + n) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (do_stats && tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        t1 += red[(w * BN + tid) * 2 + 0];
+        t2 += red[(w * BN + tid) * 2 + 1];
+      }
+      *((float2*)a.stats + (size_t)mt * a.Ntot + n0 + tid) = make_float2(t1, t2);
+    }
+    constexpr int CPR = BN * E::ES / 16, NST = BM * CPR / NTHR;
+    const int cc = tid & (CPR - 1);
+    const int nn = n0 + cc * E::VEC;
+    const size_t pix0 = ((size_t)(ub * H + uy0)) * W + ux0;
+    T* dbase;
+    size_t pstride;
+    if (nn < a.CO1) { dbase = (T*)a.out + pix0 * a.CO1 + nn; pstride = a.CO1; }
+    else { dbase = (T*)a.out2 + pix0 * a.CO2 + (nn - a.CO1); pstride = a.CO2; }
+    const size_t rstride = (size_t)W * pstride;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int m = (tid + i * NTHR) / CPR;
+      const int ty = m >> TWL, tx = m & (TW - 1);
+      const uint4 v = *(const uint4*)(ot + m * OP + cc * 16);
+      if (FULL || (uy0 + ty < H && ux0 + tx < W)) *(uint4*)(dbase + ty * rstride + tx * pstride) = v;
+    }
+  };
+
+  decode(mt, ub, uy0, ux0);
+  load_patch(ub, uy0, ux0);
+  store_patch();
+  __syncthreads();
+  for (;;) {
+    const int mnext = mt + GW;
+    const bool has_next = mnext < mt_end;
+    int nb = ub, ny0 = uy0, nx0 = ux0;
+    if (has_next) {
+      decode(mnext, nb, ny0, nx0);
+      load_patch(nb, ny0, nx0);            // flies under the MFMA loop below
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mf][r] = 0.f;
+    for (int kc = 0; kc < nchunks; ++kc) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const char* pb = smem + kc * PB + (tap / 3) * ROWP + (tap % 3) * PIXB;
+        const char* wb = smem + (kc * 9 + tap) * WTAP + laneB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const uint4 fb = *(const uint4*)(wb + kk * 32);
+          uint4 fa[MF];
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) fa[mf] = *(const uint4*)(pb + laneA[mf] + kk * 32);
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) Mma<T>::run(fa[mf], fb, acc[mf]);
+        }
+      }
+    }
+    __syncthreads();                       // patch fully consumed: its LDS becomes the output staging tile
+    if ((uy0 + TH <= H) && (ux0 + TW <= W)) epilogue_t(std::true_type{});
+    else epilogue_t(std::false_type{});
+    if (!has_next) break;
+    __syncthreads();
+    store_patch();
+    mt = mnext; ub = nb; uy0 = ny0; ux0 = nx0;
+    __syncthreads();
+  }
+}
+
+template <typename T, int TWL, bool PRO>
+int launch_ws(ConvArgs a, hipStream_t st) {
+  using E = ET<T>;
+  constexpr int BM = 256, BN = 64, NTHR = 512;
+  constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
+  constexpr int ROWP = (PW * PIXB + 255) & ~255;
+  constexpr size_t lds = 2 * (size_t)PH * ROWP + 2 * 9 * (size_t)BN * PIXB + NTHR * 16;
+  static_assert(lds <= 160 * 1024, "conv_ws: LDS exceeds 160 KiB");
+  static_assert(BM * (BN * E::ES + 16) + 4 * BN * 8 <= 2 * PH * ROWP, "output staging tile fits in the patch region");
+  a.twl = TWL;
+  a.tiles_x = cdiv(a.W, TW);
+  a.tiles_y = cdiv(a.H, TH);
+  const int NT = a.Ntot / BN;
+  const int MT = a.B * a.tiles_x * a.tiles_y;
+  int gw = num_cus() / 8;                                  // one workgroup per CU
+  gw -= gw % NT;
+  const int need = ((MT + 7) / 8) * NT;
+  if (gw > need) gw = need;
+  if (gw < NT) gw = NT;
+  a.persistent = 1;
+  auto kern = conv_ws_kernel<T, TWL, PRO>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SEGK_FAIL(-3, "conv_ws: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(8 * gw), dim3(NTHR), lds, st, a);
+  SEGK_CHECK_LAUNCH("conv_ws");
+  return 0;
+}
+
 template <typename T, int GEO, int TWL, int WM, int WN, int MF, int NF, int PBUF, bool PRO>
 int launch_pro(ConvArgs a, hipStream_t st) {
   using E = ET<T>;
@@ -450,6 +724,13 @@ int launch_geo(const ConvArgs& a, hipStream_t st) {
   // BN must divide N; with the pixel-shuffle store a channel tile must not straddle two taps.
   const int unit = a.shuffle ? a.CO1 : a.Ntot;
   const bool wide = a.W > 16;                      // 8x32 tiles unless the image is at most 16 wide
+  if constexpr (GEO == 0 && sizeof(T) == 2) {
+    // narrow high-resolution layers: weight-stationary streaming kernel (64-channel tiles)
+    if (segk_conv_use_ws(a.CA + a.CB, a.Ntot, sizeof(T) == 2 ? SEGK_DT_BF16 : SEGK_DT_F32)) {
+      if (a.scale) return wide ? launch_ws<T, 5, true>(a, st) : launch_ws<T, 4, true>(a, st);
+      return wide ? launch_ws<T, 5, false>(a, st) : launch_ws<T, 4, false>(a, st);
+    }
+  }
   if (unit % 128 == 0)                             // 256 px x 128 ch, 8 waves
     return wide ? launch_cfg<T, GEO, 5, 4, 2, 2, 2, 2>(a, st) : launch_cfg<T, GEO, 4, 4, 2, 2, 2, 2>(a, st);
   if constexpr (GEO == 0) {

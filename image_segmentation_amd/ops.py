@@ -318,22 +318,23 @@ class DoubleConvFn(torch.autograd.Function):
         xb_t, pB, CBp = (None, 0, 0) if xb is None else _raw(xb, dtype)
         w1p = mod.cache.get(("w1f", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 0))
         w2p = mod.cache.get(("w2f", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 0))
-        tiles = _lib.query("segk_conv_tiles", B, H, W, Coutp)
+        tiles1 = _lib.query("segk_conv_tiles", B, H, W, CAp + CBp, Coutp, _DT[dtype])
+        tiles2 = _lib.query("segk_conv_tiles", B, H, W, Coutp, Coutp, _DT[dtype])
         P = B * H * W
 
         z1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        st1 = _f32(_lib.query("segk_bn_stats_floats", tiles, Coutp), dev) if training else None
+        st1 = _f32(_lib.query("segk_bn_stats_floats", tiles1, Coutp), dev) if training else None
         conv3x3(xa_t, pA, CAp, pB, CBp, w1p, z1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, stats=st1, alg=(CA + CB, Cout))
         mom1 = bn1.momentum if bn1.momentum is not None else 0.1
-        sc1, sh1, mu1, rs1 = bn_finalize(st1, tiles, Cout, P, None if b1 is None else _param_f32(b1), _param_f32(g1),
+        sc1, sh1, mu1, rs1 = bn_finalize(st1, tiles1, Cout, P, None if b1 is None else _param_f32(b1), _param_f32(g1),
                                          _param_f32(be1), bn1.running_mean, bn1.running_var, mom1, bn1.eps, training,
                                          dev)
         z2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        st2 = _f32(_lib.query("segk_bn_stats_floats", tiles, Coutp), dev) if training else None
+        st2 = _f32(_lib.query("segk_bn_stats_floats", tiles2, Coutp), dev) if training else None
         conv3x3(z1, z1.data_ptr(), Coutp, 0, 0, w2p, z2.data_ptr(), Coutp, 0, 0, B, H, W, dtype, scale=sc1, shift=sh1,
                 stats=st2, alg=(Cout, Cout))
         mom2 = bn2.momentum if bn2.momentum is not None else 0.1
-        sc2, sh2, mu2, rs2 = bn_finalize(st2, tiles, Cout, P, None if b2 is None else _param_f32(b2), _param_f32(g2),
+        sc2, sh2, mu2, rs2 = bn_finalize(st2, tiles2, Cout, P, None if b2 is None else _param_f32(b2), _param_f32(g2),
                                          _param_f32(be2), bn2.running_mean, bn2.running_var, mom2, bn2.eps, training,
                                          dev)
         if training:

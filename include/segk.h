@@ -54,7 +54,7 @@ int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cin
  * scale/shift != NULL: the producer layer's BatchNorm+ReLU is applied to srcA on load (fused prologue).
  * stats != NULL: per-tile per-channel (sum, sumsq) partials [segk_conv_tiles()][CO1+CO2][2] for
  * training-mode BatchNorm (finish with segk_bn_finalize).  For the data gradient pass mode-1 weights. */
-int segk_conv_tiles(int B, int H, int W, int Cout);   /* Cout = CO1+CO2 (padded) of the segk_conv3x3 call */
+int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype);   /* padded CA+CB and CO1+CO2 of the call */
 /* floats to allocate for `stats`: the [tiles][Cp][2] partials plus the scratch segk_bn_finalize reduces through */
 int segk_bn_stats_floats(int tiles, int Cp);
 int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const float* bias, const float* scale,

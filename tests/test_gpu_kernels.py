@@ -61,7 +61,7 @@ def _conv_direct(ops, x, w, dtype, xb=None, scale=None, shift=None, stats=False,
     wp = ops.pack_conv(dev(w), CA, CB, dtype, mode)
     Coutp = ops.pad32(Cout)
     out = torch.empty((B, H, W, Coutp), dtype=dtype, device="cuda")
-    tiles = _lib.query("segk_conv_tiles", B, H, W, Coutp)
+    tiles = _lib.query("segk_conv_tiles", B, H, W, CAp + CBp, Coutp, 1 if dtype == torch.bfloat16 else 0)
     st = torch.zeros((_lib.query("segk_bn_stats_floats", tiles, Coutp),), dtype=torch.float32, device="cuda") if stats else None
     ops.conv3x3(xa, pa, CAp, pb, CBp, wp, out.data_ptr(), Coutp, 0, 0, B, H, W, dtype,
                 scale=None if scale is None else dev(scale), shift=None if shift is None else dev(shift), stats=st)

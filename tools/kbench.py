@@ -49,7 +49,7 @@ def main():
         fl = 2.0 * B * hw * hw * 9 * cin * cout
         by = B * hw * hw * (cin + cout) * 2
         if args.what in ("conv", "all"):
-            tiles = _lib.query("segk_conv_tiles", B, hw, hw, cout)
+            tiles = _lib.query("segk_conv_tiles", B, hw, hw, cin, cout, 1)
             st = torch.empty((_lib.query("segk_bn_stats_floats", tiles, cout),), dtype=torch.float32, device="cuda")
             us = timeit(lambda: ops.conv3x3(x, x.data_ptr(), cin, 0, 0, wp, out.data_ptr(), cout, 0, 0, B, hw, hw, dt,
                                             scale=sc, shift=sh, stats=st), args.iters)
