@@ -248,19 +248,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
         for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
   };
 
-  // one tap (two MFMA k-steps over the 64-byte chunk) against LDS
-  auto mma_tap = [&](const char* pb, const char* wb) {
+  // one pipeline step against LDS: TPS taps x two MFMA k-steps, with the fragment reads of sub-step i+1
+  // issued BEFORE the MFMAs of sub-step i (register double buffer) so LDS latency hides under the matrix pipe
+  auto mma_step = [&](const char* pb, const char* wb) {
+    constexpr int NSUB = TPS * 2;
+    uint4 fa[2][MF], fb[2][NF];
+    auto rd = [&](int i, uint4 (&A)[MF], uint4 (&Bf)[NF]) {
+      const int t = i >> 1, kk = i & 1;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      uint4 fa[MF], fb[NF];
+      for (int mf = 0; mf < MF; ++mf) A[mf] = *(const uint4*)(pb + laneA[mf] + t * PIXB + kk * 32);
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) fa[mf] = *(const uint4*)(pb + laneA[mf] + kk * 32);
+      for (int nf = 0; nf < NF; ++nf) Bf[nf] = *(const uint4*)(wb + laneB[nf] + t * (BN * PIXB) + kk * 32);
+    };
+    rd(0, fa[0], fb[0]);
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) fb[nf] = *(const uint4*)(wb + laneB[nf] + kk * 32);
+    for (int i = 0; i < NSUB; ++i) {
+      if (i + 1 < NSUB) rd(i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of this sub-step's MFMAs
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[mf], fb[nf], acc[mf][nf]);
+        for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[i & 1][mf], fb[i & 1][nf], acc[mf][nf]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -382,8 +391,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
       }
       const char* pb = patch0 + (PBUF == 2 ? (kc & 1) * PB : 0) + (GEO == 0 ? tg * ROWP : 0);
       const char* wb = wbuf0 + (s & 1) * WB;
-#pragma unroll
-      for (int t = 0; t < TPS; ++t) mma_tap(pb + t * PIXB, wb + t * (BN * PIXB));
+      mma_step(pb, wb);
       // write-late: the data issued above (or a step / chunk earlier) lands in the other LDS buffers
       if (!last_step) store_w((s + 1) & 1);
       if (tg == SPC - 1 && more_chunks && PBUF == 2) store_patch(((kc + 1) & 1) * PB);
@@ -616,19 +624,25 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mf][r] = 0.f;
     for (int kc = 0; kc < nchunks; ++kc) {
+      // 18 sub-steps (9 taps x 2 k-steps); fragment reads run one sub-step ahead of the MFMAs
+      const char* pbase = smem + kc * PB;
+      const char* wbase = smem + kc * 9 * WTAP + laneB;
+      uint4 fa[2][MF], fb[2];
+      auto rd = [&](int i, uint4 (&A)[MF], uint4& Bf) {
+        const int tap = i >> 1, kk = i & 1;
+        const char* pb = pbase + (tap / 3) * ROWP + (tap % 3) * PIXB + kk * 32;
+        Bf = *(const uint4*)(wbase + tap * WTAP + kk * 32);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const char* pb = smem + kc * PB + (tap / 3) * ROWP + (tap % 3) * PIXB;
-        const char* wb = smem + (kc * 9 + tap) * WTAP + laneB;
+        for (int mf = 0; mf < MF; ++mf) A[mf] = *(const uint4*)(pb + laneA[mf]);
+      };
+      rd(0, fa[0], fb[0]);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const uint4 fb = *(const uint4*)(wb + kk * 32);
-          uint4 fa[MF];
+      for (int i = 0; i < 18; ++i) {
+        if (i + 1 < 18) rd(i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of this sub-step's MFMAs
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) fa[mf] = *(const uint4*)(pb + laneA[mf] + kk * 32);
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf) Mma<T>::run(fa[mf], fb, acc[mf]);
-        }
+        for (int mf = 0; mf < MF; ++mf) Mma<T>::run(fa[i & 1][mf], fb[i & 1], acc[mf]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();                       // patch fully consumed: its LDS becomes the output staging tile
