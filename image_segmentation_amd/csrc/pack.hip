@@ -93,26 +93,51 @@ __global__ void pack_convt_weight_kernel(const float* __restrict__ w, T* __restr
   }
 }
 
-// Sum S gradient slabs [S][Np][taps][Kp] (fp32) and scatter into the reference layout.
-//  kind 0: Conv2d OIHW        grad[n=co][ci(k)][tap]
-//  kind 1: ConvTranspose IOHW grad[n=ci][k=co][tap]   (no dual map)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, float* __restrict__ grad, int N, int CA,
-                                    int CB, int Np, int CAp, int CBp, int taps, int kind) {
-  // one thread per OUTPUT element (coalesced stores); the strided slab reads are absorbed by L2
+// Sum S gradient slabs [S][Np][taps][Kp] (fp32) into the dense reference-layout gradient [N][K][taps]
+// (OIHW for Conv2d, IOHW for ConvTranspose2d).  One block per output row n: the slab rows are read with
+// coalesced float4 loads (k fastest), transposed through LDS, and the row is written as one contiguous run.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int S,
+                                                           float* __restrict__ grad, int N, int CA, int CB, int Np,
+                                                           int CAp, int CBp, int taps) {
+  extern __shared__ float row[];                 // [K][taps] in output order
   const int Kp = CAp + CBp, K = CA + CB;
+  const int n = blockIdx.x;
   const long slab = (long)Np * taps * Kp;
-  const long total = (long)N * K * taps;
+  const float* base = slabs + (long)n * taps * Kp;
+  const int nvec = taps * Kp / 4;                // Kp % 32 == 0
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < S; ++t) {                // fixed order: bit-stable
+      const float4 x = *(const float4*)(base + (long)t * slab + (long)v * 4);
+      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+    const int e = v * 4, tap = e / Kp, kp = e - tap * Kp;
+    const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = kp + j;
+      const int k = q < CAp ? (q < CA ? q : -1) : (q - CAp < CB ? CA + q - CAp : -1);
+      if (k >= 0) row[k * taps + tap] = vals[j];
+    }
+  }
+  __syncthreads();
+  float* dst = grad + (long)n * K * taps;
+  for (int i = threadIdx.x; i < K * taps; i += 256) dst[i] = row[i];
+}
+
+// stage 1 for large split-K factors: fold slab s into slab (s mod G), in place, float4-wide and fully parallel
+__global__ __launch_bounds__(256) void slab_fold_kernel(float* __restrict__ slabs, int S, int G, long slab_vec) {
+  const long total = slab_vec * G;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int tap = (int)(i % taps);
-    long r = i / taps;
-    const int k = (int)(r % K);
-    const int n = (int)(r / K);
-    const int kp = k < CA ? k : CAp + (k - CA);
-    const long src = ((long)n * taps + tap) * Kp + kp;
-    float s = 0.f;
-    for (int t = 0; t < S; ++t) s += slabs[(long)t * slab + src];  // fixed order: bit-stable
-    grad[i] = s;
-    (void)kind;
+    const int g = (int)(i / slab_vec);
+    const long v = i - (long)g * slab_vec;
+    float4* p = (float4*)slabs + (long)g * slab_vec + v;
+    float4 acc = *p;
+    for (int t = g + G; t < S; t += G) {           // fixed order: bit-stable
+      const float4 x = ((const float4*)slabs)[(long)t * slab_vec + v];
+      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+    *p = acc;
   }
 }
 
@@ -184,9 +209,17 @@ int segk_wgrad_reduce_impl(const float* slabs, int S, float* grad, int N, int CA
                            int taps, hipStream_t st) {
   SEGK_REQUIRE(slabs && grad && S > 0 && N > 0 && CA > 0 && CB >= 0 && Np >= N && CAp >= CA && CBp >= CB && taps > 0,
                "wgrad_reduce: bad arguments");
-  const long total = (long)N * (CA + CB) * taps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, st, slabs, S, grad, N, CA, CB, Np, CAp,
-                     CBp, taps, 0);
+  constexpr int G = 8;
+  if (S > 2 * G) {   // many thin slabs (narrow layers): fold them to G slabs first so stage 2 stays parallel
+    const long slab_vec = (long)Np * taps * (CAp + CBp) / 4;
+    hipLaunchKernelGGL(slab_fold_kernel, dim3(grid_for(slab_vec * G)), dim3(256), 0, st, const_cast<float*>(slabs), S, G,
+                       slab_vec);
+    SEGK_CHECK_LAUNCH("slab_fold");
+    S = G;
+  }
+  const size_t lds = (size_t)(CA + CB) * taps * sizeof(float);
+  SEGK_REQUIRE(lds <= 64 * 1024, "wgrad_reduce: a gradient row of %zu bytes exceeds the LDS staging limit", lds);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(N), dim3(256), lds, st, slabs, S, grad, N, CA, CB, Np, CAp, CBp, taps);
   SEGK_CHECK_LAUNCH("wgrad_reduce");
   return 0;
 }
