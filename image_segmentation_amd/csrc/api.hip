@@ -96,9 +96,10 @@ int segk_convt2x2_dgrad(const void* dout, const void* wpacked, void* din, int B,
 }
 
 int segk_wgrad(const void* dz, const void* srcA, const void* srcB, const float* scale, const float* shift, float* slabs,
-               int S, int B, int H, int W, int CD, int CA, int CB, int geo, int dtype, segk_stream_t s) {
+               const void* zeros, int S, int B, int H, int W, int CD, int CA, int CB, int geo, int dtype,
+               segk_stream_t s) {
   WgradArgs a{};
-  a.dz = dz; a.srcA = srcA; a.srcB = srcB; a.scale = scale; a.shift = shift; a.slabs = slabs;
+  a.dz = dz; a.srcA = srcA; a.srcB = srcB; a.scale = scale; a.shift = shift; a.slabs = slabs; a.zeros = zeros;
   a.B = B; a.H = H; a.W = W; a.CD = CD; a.CA = CA; a.CB = CB; a.S = S;
   return segk_wgrad_launch(a, geo, dtype, (hipStream_t)s);
 }

@@ -32,6 +32,7 @@ struct WgradArgs {
   const float* scale;   // optional BN+ReLU prologue on the shifted operand
   const float* shift;
   float* slabs;         // [S][CD][taps][CA+CB] fp32 partial weight gradients
+  const void* zeros;    // >= 64 bytes of zeros in device memory (source of out-of-image pixels for the DMA path)
   int B, H, W;          // grid of the un-shifted operand
   int CD, CA, CB;
   int S;                // split-K factor over spatial tiles

@@ -225,6 +225,224 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 3x3 weight gradient with LDS-DMA staging (global_load_lds: no staging VGPRs, no ds_write pass).
+//   U = the un-shifted operand  (8 x 16 pixel tile, WU blocks of 32 channels)
+//   V = the tap-shifted operand (10 x 18 patch,     WV blocks), raw, out-of-image pixels read a zero page
+// Both tiles are double-buffered in LDS; the DMA of tile t+1 flies under the MFMAs of tile t.  The three
+// kx-fragments of a patch row serve taps (ky, kx) of three consecutive dz rows, so they rotate through
+// registers and each dz row fetches ONE new patch row (6 transposing reads instead of 18).
+// PRO (the second conv of a block: its input is relu(bn(z1))): the roles are swapped so that the operand
+// needing the BatchNorm+ReLU transform is the un-shifted one -- the transform is then applied to ONE
+// fragment per dz row, in registers, with the lane's own channel constants, and the shifted operand (dz)
+// needs no transform and gets exact-zero halos from the zero page.  Swapping A/B in the MFMA keeps the
+// accumulator oriented [co][ci]; the tap index mirrors (tap -> 8 - tap).
+template <int WC, int WI, bool PRO>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
+  typedef bf16_t T;
+  constexpr int R = 8, NTAPS = 9, BLKP = 64;
+  constexpr int WU = PRO ? WI : WC, WV = PRO ? WC : WI;
+  constexpr int NU = R * 16, NV = 192;                    // pixels per block region (patch: 180 used)
+  constexpr int UB = WU * NU * BLKP, VB = WV * NV * BLKP, BUF = UB + VB;
+  constexpr int NINSTR = WU * 8 + WV * 12;                // 1 KiB DMA wave-instructions per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) s16x4* lds_v4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W;
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + R - 1) / R;
+  const int ntiles = a.B * tiles_y * tiles_x;
+  const int KT = (a.CA + a.CB) / (32 * WI), NCT = (a.CD / (32 * WC)) * KT;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int s = lid / NCT, ct = lid - s * NCT;
+  const int n0 = (ct / KT) * 32 * WC, k0 = (ct % KT) * 32 * WI;
+
+  // operand roles
+  const T* srck; int SCk, kc0;                            // the k-tile's source (first or second concat operand)
+  if (k0 < a.CA) { srck = (const T*)a.srcA; SCk = a.CA; kc0 = k0; }
+  else { srck = (const T*)a.srcB; SCk = a.CB; kc0 = k0 - a.CA; }
+  const T* const ubase = PRO ? srck + kc0 : (const T*)a.dz + n0;
+  const int UC = PRO ? SCk : a.CD;
+  const T* const vbase = PRO ? (const T*)a.dz + n0 : srck + kc0;
+  const int VC = PRO ? a.CD : SCk;
+  const char* const zeros = (const char*)a.zeros;
+
+  const int lp = lane >> 2, lc = lane & 3;                // pixel-in-chunk / 16-byte piece of the lane
+  auto issue_tile = [&](int t, int bufsel) {
+    const int bimg = t / (tiles_y * tiles_x);
+    const int rem = t - bimg * tiles_y * tiles_x;
+    const int y0 = (rem / tiles_x) * R, x0 = (rem % tiles_x) * 16;
+    char* const bb = smem + bufsel * BUF;
+#pragma unroll
+    for (int i = 0; i < (NINSTR + 3) / 4; ++i) {
+      const int j = wave + 4 * i;                          // wave-uniform
+      if (j >= NINSTR) break;
+      const char* src;
+      char* dst;
+      if (j < WU * 8) {
+        const int blk = j >> 3, r = j & 7;
+        const int gy = y0 + r, gx = x0 + lp;
+        const bool ok = gy < H && gx < W;
+        src = ok ? (const char*)(ubase + ((size_t)(bimg * H + gy) * W + gx) * UC + blk * 32 + lc * 8) : zeros + lc * 16;
+        dst = bb + blk * (NU * BLKP) + r * 1024;
+      } else {
+        const int jj = j - WU * 8;
+        const int blk = jj / 12, ch = jj - blk * 12;
+        const int pp = ch * 16 + lp;
+        const int py = pp / 18, px = pp - py * 18;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        const bool ok = pp < 180 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        src = ok ? (const char*)(vbase + ((size_t)(bimg * H + gy) * W + gx) * VC + blk * 32 + lc * 8) : zeros + lc * 16;
+        dst = bb + UB + blk * (NV * BLKP) + ch * 1024;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  const bool computes = wave < WC * WI;
+  const int wc = wave / WI, wi = wave - wc * WI;
+  const int wu = PRO ? wi : wc, wv = PRO ? wc : wi;
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // lane -> (group g: channel half gsub, k half h; q = pixel row of the 4x16 block, p = 4-col piece)
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int gsub = g & 1, h = g >> 1;
+  const int coff = (16 * gsub + 4 * p) * 2;
+  const int xa = 8 * h + q;                               // pixel column of read 0; read 1 is +4
+  float psc = 1.f, psh = 0.f;
+  if (PRO) {
+    const int c = kc0 + wu * 32 + 16 * gsub + i16;         // the lane's own channel of the un-shifted operand
+    psc = a.scale[c];
+    psh = a.shift[c];
+  }
+  auto frag = [&](const char* base, int pix) {
+    const s16x4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + pix * BLKP + coff));
+    const s16x4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + (pix + 4) * BLKP + coff));
+    return __builtin_shufflevector(f0, f1, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  // BatchNorm(scale, shift) + ReLU on the 8 pixels of one channel; vmask bit j = pixel j lies inside the image
+  auto transform = [&](s16x8 v, unsigned vmask) {
+    const uint4 raw = __builtin_bit_cast(uint4, v);
+    float f[8];
+    unpack16<T>(raw, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = fmaxf(fmaf(f[j], psc, psh), 0.f);
+      f[j] = ((vmask >> j) & 1) ? f[j] : 0.f;
+    }
+    return __builtin_bit_cast(s16x8, pack16<T>(f));
+  };
+
+  int t = s, cur = 0;
+  if (t < ntiles) issue_tile(t, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (; t < ntiles; t += a.S) {
+    if (t + a.S < ntiles) issue_tile(t + a.S, cur ^ 1);    // DMA of the next tile flies under the MFMAs
+    if (computes) {
+      const char* const ub = smem + cur * BUF + wu * (NU * BLKP);
+      const char* const vb = smem + cur * BUF + UB + wv * (NV * BLKP);
+      unsigned xmask = 0xffu, rows_ok = R;
+      if (PRO) {                                           // partial tiles: mask pixels outside the image
+        const int bimg = t / (tiles_y * tiles_x);
+        const int rem = t - bimg * tiles_y * tiles_x;
+        const int y0 = (rem / tiles_x) * R, x0 = (rem % tiles_x) * 16;
+        rows_ok = (unsigned)min(R, H - y0);
+        xmask = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)   // fragment element j = pixel column 8h + j of the tile row (two 4-row blocks)
+          xmask |= (x0 + 8 * h + j < W ? 1u : 0u) << j;
+      }
+      s16x8 fv[3][3], fu[2];
+#pragma unroll
+      for (int y = 0; y < 3; ++y)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) fv[y][kx] = frag(vb, y * 18 + xa + kx);
+      fu[0] = frag(ub, xa);
+      if (PRO) fu[0] = transform(fu[0], rows_ok > 0 ? xmask : 0u);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r + 1 < R) {
+          fu[(r + 1) & 1] = frag(ub, (r + 1) * 16 + xa);
+          if (PRO) fu[(r + 1) & 1] = transform(fu[(r + 1) & 1], (unsigned)(r + 1) < rows_ok ? xmask : 0u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 fur = __builtin_bit_cast(bf16x8, fu[r & 1]);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {                   // ky = 0 consumes patch row r ...
+          const bf16x8 fvr = __builtin_bit_cast(bf16x8, fv[r % 3][kx]);
+          constexpr int dummy = 0; (void)dummy;
+          const int ti = PRO ? 8 - kx : kx;
+          acc[ti] = PRO ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fvr, fur, acc[ti], 0, 0, 0)
+                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fur, fvr, acc[ti], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 1 < R) {                                   // ... whose register slot then takes patch row r+3
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) fv[r % 3][kx] = frag(vb, (r + 3) * 18 + xa + kx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ky = 1; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const bf16x8 fvr = __builtin_bit_cast(bf16x8, fv[(r + ky) % 3][kx]);
+            const int ti = PRO ? 8 - (ky * 3 + kx) : ky * 3 + kx;
+            acc[ti] = PRO ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fvr, fur, acc[ti], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fur, fvr, acc[ti], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile's DMA has landed
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  if (computes) {
+    const int K = a.CA + a.CB;
+    const int col = lane & 31, lh = lane >> 5;
+    float* const slab = a.slabs + (size_t)s * a.CD * NTAPS * K;
+#pragma unroll
+    for (int tp = 0; tp < NTAPS; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        slab[((size_t)(n0 + wc * 32 + row) * NTAPS + tp) * K + k0 + wi * 32 + col] = acc[tp][r];
+      }
+  }
+}
+
+template <int WC, int WI, bool PRO>
+int launch_dma(const WgradArgs& a, hipStream_t st) {
+  constexpr int WU = PRO ? WI : WC, WV = PRO ? WC : WI;
+  constexpr size_t lds = 2 * ((size_t)WU * 128 * 64 + (size_t)WV * 192 * 64);
+  static_assert(lds <= 160 * 1024, "wgrad_dma: LDS exceeds 160 KiB");
+  const int NCT = (a.CD / (32 * WC)) * ((a.CA + a.CB) / (32 * WI));
+  auto kern = wgrad_dma_kernel<WC, WI, PRO>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SEGK_FAIL(-3, "wgrad_dma: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3(256), lds, st, a);
+  SEGK_CHECK_LAUNCH("wgrad_dma");
+  return 0;
+}
+
+template <int WC, int WI>
+int launch_dma_pro(const WgradArgs& a, hipStream_t st) {
+  return a.scale ? launch_dma<WC, WI, true>(a, st) : launch_dma<WC, WI, false>(a, st);
+}
+
 template <typename T, int GEO, int WC, int WI>
 int launch_cfg(const WgradArgs& a, hipStream_t st) {
   using G = WG<T, GEO>;
@@ -246,6 +464,14 @@ template <typename T, int GEO>
 int launch_geo(const WgradArgs& a, hipStream_t st) {
   const bool wc2 = a.CD % 64 == 0;
   const bool wi2 = a.CA % 64 == 0 && a.CB % 64 == 0;
+  if constexpr (GEO == 0 && sizeof(T) == 2) {
+    if (a.zeros) {           // bf16 3x3: LDS-DMA kernel (needs the caller's zero page)
+      if (wc2 && wi2) return launch_dma_pro<2, 2>(a, st);
+      if (wc2) return launch_dma_pro<2, 1>(a, st);
+      if (wi2) return launch_dma_pro<1, 2>(a, st);
+      return launch_dma_pro<1, 1>(a, st);
+    }
+  }
   if (wc2 && wi2) return launch_cfg<T, GEO, 2, 2>(a, st);
   if (wc2) return launch_cfg<T, GEO, 2, 1>(a, st);
   if (wi2) return launch_cfg<T, GEO, 1, 2>(a, st);

@@ -227,6 +227,21 @@ def conv3x3(srcA, ptrA, CAp, ptrB, CBp, wpacked, out_ptr, CO1p, out2_ptr, CO2p, 
                   _p(stats), B, H, W, CAp, CBp, CO1p, CO2p, _DT[dtype], _stream())
 
 
+_ZERO_PAGES = {}
+
+
+def _zero_page(dev):
+    """64 zero bytes per device: the halo source of the LDS-DMA weight-gradient kernel."""
+    key = torch.device(dev)
+    if key.type == "cuda" and key.index is None:
+        key = torch.device("cuda", torch.cuda.current_device())
+    z = _ZERO_PAGES.get(key)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=key)
+        _ZERO_PAGES[key] = z
+    return z
+
+
 def wgrad(dz_ptr, CDp, ptrA, CAp, ptrB, CBp, B, H, W, geo, dtype, dev, scale=None, shift=None, alg=None):
     """Returns the slabs tensor and S (split-K factor)."""
     taps = {0: 9, 1: 1, 2: 4}[geo]
@@ -241,8 +256,8 @@ def wgrad(dz_ptr, CDp, ptrA, CAp, ptrB, CBp, B, H, W, geo, dtype, dev, scale=Non
     slabs = _f32(S * CDp * taps * (CAp + CBp), dev)
     tag = {0: "wgrad3x3", 1: "wgrad1x1", 2: "wgrad_convt"}[geo]
     with _span(tag, 2.0 * P * taps * cd * ck, (P * cd + pk * ck) * e + 4.0 * taps * cd * ck):
-        _lib.call("segk_wgrad", dz_ptr, ptrA, ptrB, _p(scale), _p(shift), slabs.data_ptr(), S, B, H, W, CDp, CAp, CBp,
-                  geo, _DT[dtype], _stream())
+        _lib.call("segk_wgrad", dz_ptr, ptrA, ptrB, _p(scale), _p(shift), slabs.data_ptr(), _zero_page(dev).data_ptr(),
+                  S, B, H, W, CDp, CAp, CBp, geo, _DT[dtype], _stream())
     return slabs, S
 
 

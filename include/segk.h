@@ -80,7 +80,9 @@ int segk_convt2x2_dgrad(const void* dout, const void* wpacked, void* din, int B,
  * scale/shift: BatchNorm+ReLU prologue on srcA (the conv input is relu(bn(z)) of the previous conv). */
 int segk_wgrad_tiles(int B, int H, int W, int geo, int dtype);
 int segk_wgrad(const void* dz, const void* srcA, const void* srcB, const float* scale, const float* shift,
-               float* slabs, int S, int B, int H, int W, int CD, int CA, int CB, int geo, int dtype, segk_stream_t s);
+               float* slabs, const void* zeros64, int S, int B, int H, int W, int CD, int CA, int CB, int geo,
+               int dtype, segk_stream_t s);   /* zeros64: >= 64 zero bytes in device memory (halo source of the
+                                                  LDS-DMA path); NULL selects the register-staged kernel */
 int segk_wgrad_reduce(const float* slabs, int S, float* grad, int N, int CA, int CB, int Np, int CAp, int CBp,
                       int taps, segk_stream_t s);
 
