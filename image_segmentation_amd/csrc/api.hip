@@ -57,10 +57,9 @@ int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype) {
 }
 
 int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const float* bias, const float* scale,
-                 const float* shift, void* out, void* out2, float* stats, const void* zeros, int B, int H, int W,
-                 int CA, int CB, int CO1, int CO2, int dtype, segk_stream_t s) {
+                 const float* shift, void* out, void* out2, float* stats, int B, int H, int W, int CA, int CB, int CO1,
+                 int CO2, int dtype, segk_stream_t s) {
   ConvArgs a{};
-  a.zeros = zeros;
   a.srcA = srcA; a.srcB = srcB; a.w = wpacked; a.bias = bias; a.scale = scale; a.shift = shift;
   a.out = out; a.out2 = out2; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.CA = CA; a.CB = CB; a.Ntot = CO1 + CO2; a.CO1 = CO1; a.CO2 = CO2;

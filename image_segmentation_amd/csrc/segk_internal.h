@@ -19,7 +19,6 @@ struct ConvArgs {
   int twl, tiles_x, tiles_y;
   int unshuf, shuffle;
   int persistent;       // set by the launcher
-  const void* zeros;    // >= 64 zero bytes in device memory (halo source of the LDS-DMA kernels); may be null
 };
 int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st);
 int segk_conv_use_ws(int cin_p, int n_p, int dtype);   // weight-stationary variant applies

@@ -239,8 +239,7 @@ def conv3x3(srcA, ptrA, CAp, ptrB, CBp, wpacked, out_ptr, CO1p, out2_ptr, CO2p, 
     P, e = B * H * W, _es(dtype)
     with _span(tag, 2.0 * P * 9 * cin * cout, P * (cin + cout) * e + 9.0 * cin * cout * e):
         _lib.call("segk_conv3x3", ptrA, ptrB, wpacked.data_ptr(), 0, _p(scale), _p(shift), out_ptr, out2_ptr,
-                  _p(stats), _zero_page(wpacked.device).data_ptr(), B, H, W, CAp, CBp, CO1p, CO2p, _DT[dtype],
-                  _stream())
+                  _p(stats), B, H, W, CAp, CBp, CO1p, CO2p, _DT[dtype], _stream())
 
 
 def wgrad(dz_ptr, CDp, ptrA, CAp, ptrB, CBp, B, H, W, geo, dtype, dev, scale=None, shift=None, alg=None):

@@ -58,8 +58,8 @@ int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype);   /* pad
 /* floats to allocate for `stats`: the [tiles][Cp][2] partials plus the scratch segk_bn_finalize reduces through */
 int segk_bn_stats_floats(int tiles, int Cp);
 int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const float* bias, const float* scale,
-                 const float* shift, void* out, void* out2, float* stats, const void* zeros64, int B, int H, int W,
-                 int CA, int CB, int CO1, int CO2, int dtype, segk_stream_t s);   /* zeros64: see segk_wgrad */
+                 const float* shift, void* out, void* out2, float* stats, int B, int H, int W, int CA, int CB,
+                 int CO1, int CO2, int dtype, segk_stream_t s);
 /* Conv2d 1x1 (clip/clipunet.py:84,122): same contract, taps = 1 */
 int segk_conv1x1(const void* srcA, const void* wpacked, const float* bias, void* out, int B, int H, int W, int CA,
                  int CO, int dtype, segk_stream_t s);
