@@ -185,15 +185,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // partials [NB][C][2] -> dgamma, dbeta, coef = (sum_g/N, sum_gx/N)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int NB, int C,
-                                                              int C_real, double count, float* dgamma, float* dbeta,
-                                                              float* coef) {
-  __shared__ double sh[8][32][2];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int NB, int C,
+                                                               int C_real, double count, float* dgamma, float* dbeta,
+                                                               float* coef) {
+  // 32 channels x 32 row-lanes per block: the NB block partials are walked in 32 interleaved streams
+  __shared__ double sh[32][32][2];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int m = ry; m < NB; m += 8) {
+    for (int m = ry; m < NB; m += 32) {
       const float2 v = ((const float2*)part)[(size_t)m * C + c];
       s1 += (double)v.x;
       s2 += (double)v.y;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   __syncthreads();
   if (ry != 0 || c >= C) return;
   s1 = 0.0; s2 = 0.0;
-  for (int r = 0; r < 8; ++r) { s1 += sh[r][cx][0]; s2 += sh[r][cx][1]; }
+  for (int r = 0; r < 32; ++r) { s1 += sh[r][cx][0]; s2 += sh[r][cx][1]; }   // fixed order
   if (c < C_real) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
   coef[2 * c] = (float)(s1 / count);
   coef[2 * c + 1] = (float)(s2 / count);
@@ -434,7 +435,7 @@ static int bn_bwd_t(const void* dy, const void* z, void* dz, const float* scale,
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gx, gy), dim3(256), lds, st, (const T*)dy, (const T*)z, scale, shift,
                      mean, rstd, P, C, cvb, rows, part);
   SEGK_CHECK_LAUNCH("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32), dim3(256), 0, st, part, gx, C, C_real, (double)P, dgamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32), dim3(1024), 0, st, part, gx, C, C_real, (double)P, dgamma,
                      dbeta, coef);
   SEGK_CHECK_LAUNCH("bn_bwd_finalize");
   long ga = (P + rows - 1) / rows;

@@ -67,104 +67,80 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
   }
 }
 
-// dy[p][c] = sum_k dl[p][k] * W[k][c];  partial dW[k][c] = sum_p dl[p][k]*y[p][c], db[k] = sum_p dl[p][k]
+// dy[p][c] = sum_k dl[p][k] * W[k][c];  partial dW[k][c] = sum_p dl[p][k]*y[p][c], db[k] = sum_p dl[p][k].
+// Pure streaming: a thread owns one 16-byte channel vector (its weights W[k][c..c+VEC) and its dW partials
+// live in registers) and walks pixels; a row of threads covers whole contiguous pixel rows of y / dy.
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlog, const T* __restrict__ y,
                                                        const float* __restrict__ w, T* __restrict__ dy,
                                                        float* __restrict__ part, long P, long HW, int Cp, int C,
-                                                       int ncls) {
+                                                       int ncls, int cvb, int rows) {
   using E = ET<T>;
-  constexpr int PITCH = HCH * E::ES + 16;
-  extern __shared__ __attribute__((aligned(16))) char tile[];   // HT * PITCH bytes
-  __shared__ float ws[MAXC * HCH];
-  __shared__ float dls[HT * MAXC];
-  __shared__ float red[4][MAXC][HCH];
-  const int tid = threadIdx.x;
-  const int cl = tid & (HCH - 1), pg = tid >> 6;  // channel lane / pixel group (4 groups of 64 pixels)
-  const int npass = (Cp + HCH - 1) / HCH;
-  // per-thread partial sums for (k, channel cl) of every pass live in LDS-free registers: one pass at a time
-  for (int pass = 0; pass < npass; ++pass) {
-    const int c0 = pass * HCH;
-    float aw[MAXC], ab[MAXC];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;                       // [rows][cvb][MAXC*VEC + MAXC]
+  constexpr int RW = MAXC * E::VEC + MAXC;
+  const int cx = threadIdx.x % cvb, ry = threadIdx.x / cvb;
+  const int cv = blockIdx.y * cvb + cx;
+  const bool active = cv < Cp / E::VEC && ry < rows;
+  float wr[MAXC][E::VEC], aw[MAXC][E::VEC], ab[MAXC];
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
-    for (long p0 = (long)blockIdx.x * HT; p0 < P; p0 += (long)gridDim.x * HT) {
-      __syncthreads();
-      constexpr int VPR = HCH / E::VEC;
-      for (int q = tid; q < HT * VPR; q += 256) {
-        const int px = q / VPR, v = q - px * VPR;
-        uint4 d = make_uint4(0, 0, 0, 0);
-        if (p0 + px < P && c0 + v * E::VEC < Cp) d = *(const uint4*)(y + (size_t)(p0 + px) * Cp + c0 + v * E::VEC);
-        *(uint4*)(tile + px * PITCH + v * 16) = d;
-      }
-      for (int q = tid; q < MAXC * HCH; q += 256) {
-        const int k = q / HCH, c = c0 + (q - k * HCH);
-        ws[q] = (k < ncls && c < C) ? w[(size_t)k * C + c] : 0.f;
-      }
-      {
-        const long p = p0 + tid;
-        const long b = p / HW, r = p - b * HW;
+  for (int k = 0; k < MAXC; ++k) {
+    ab[k] = 0.f;
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) dls[tid * MAXC + k] = (p < P && k < ncls) ? dlog[(b * ncls + k) * HW + r] : 0.f;
-      }
-      __syncthreads();
-      // weight-gradient partials: thread (cl, pg) walks the 64 pixels of its group down one channel column
-      for (int i = 0; i < 64; ++i) {
-        const int px = pg * 64 + i;
-        const float yv = to_float<T>(*(const T*)(tile + px * PITCH + cl * E::ES));
+    for (int j = 0; j < E::VEC; ++j) {
+      const int c = cv * E::VEC + j;
+      wr[k][j] = (active && k < ncls && c < C) ? w[(size_t)k * C + c] : 0.f;
+      aw[k][j] = 0.f;
+    }
+  }
+  if (active) {
+    for (long p = (long)blockIdx.x * rows + ry; p < P; p += (long)gridDim.x * rows) {
+      const long b = p / HW, r = p - b * HW;
+      float dl[MAXC];
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) {
-          const float d = dls[px * MAXC + k];
-          aw[k] = fmaf(d, yv, aw[k]);
-          if (pass == 0 && cl == 0) ab[k] += d;
+      for (int k = 0; k < MAXC; ++k) dl[k] = (k < ncls) ? dlog[(b * ncls + k) * HW + r] : 0.f;
+      float f[E::VEC], o[E::VEC];
+      unpack16<T>(*(const uint4*)(y + (size_t)p * Cp + cv * E::VEC), f);
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) o[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        ab[k] += dl[k];
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) {
+          o[j] = fmaf(dl[k], wr[k][j], o[j]);
+          aw[k][j] = fmaf(dl[k], f[j], aw[k][j]);
         }
       }
-      __syncthreads();
-      // data gradient: thread per pixel, overwrite the tile in place, then coalesced store
-      {
-        float dl[MAXC];
-#pragma unroll
-        for (int k = 0; k < MAXC; ++k) dl[k] = dls[tid * MAXC + k];
-#pragma unroll 4
-        for (int v = 0; v < VPR; ++v) {
-          float f[E::VEC];
-#pragma unroll
-          for (int j = 0; j < E::VEC; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < MAXC; ++k) s = fmaf(dl[k], ws[k * HCH + v * E::VEC + j], s);
-            f[j] = s;
-          }
-          *(uint4*)(tile + tid * PITCH + v * 16) = pack16<T>(f);
-        }
-      }
-      __syncthreads();
-      for (int q = tid; q < HT * VPR; q += 256) {
-        const int px = q / VPR, v = q - px * VPR;
-        if (p0 + px < P && c0 + v * E::VEC < Cp)
-          *(uint4*)(dy + (size_t)(p0 + px) * Cp + c0 + v * E::VEC) = *(const uint4*)(tile + px * PITCH + v * 16);
-      }
+      *(uint4*)(dy + (size_t)p * Cp + cv * E::VEC) = pack16<T>(o);
     }
-    __syncthreads();
+  }
+  if (ry < rows) {
+    float* q = red + ((size_t)ry * cvb + cx) * RW;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) red[pg][k][cl] = aw[k];
-    __syncthreads();
-    if (pg == 0) {
-      // part layout: [block][MAXC][Cp + 1]  (last column = bias gradient)
-      float* dst = part + (size_t)blockIdx.x * MAXC * (Cp + 1);
+    for (int k = 0; k < MAXC; ++k) {
 #pragma unroll
-      for (int k = 0; k < MAXC; ++k)
-        if (c0 + cl < Cp) dst[k * (Cp + 1) + c0 + cl] = red[0][k][cl] + red[1][k][cl] + red[2][k][cl] + red[3][k][cl];
+      for (int j = 0; j < E::VEC; ++j) q[k * E::VEC + j] = aw[k][j];
+      q[MAXC * E::VEC + k] = ab[k];
     }
-    if (pass == 0) {
-      __syncthreads();
-      if (cl == 0)
+  }
+  __syncthreads();
+  if (ry == 0 && cv < Cp / E::VEC) {
+    // part layout: [block][MAXC][Cp + 1]  (last column = bias gradient, written by channel vector 0)
+    float* dst = part + (size_t)blockIdx.x * MAXC * (Cp + 1);
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) red[pg][k][0] = ab[k];
-      __syncthreads();
-      if (tid < MAXC)
-        part[(size_t)blockIdx.x * MAXC * (Cp + 1) + tid * (Cp + 1) + Cp] =
-            red[0][tid][0] + red[1][tid][0] + red[2][tid][0] + red[3][tid][0];
+    for (int k = 0; k < MAXC; ++k) {
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) {
+        float s = 0.f;
+        for (int r2 = 0; r2 < rows; ++r2) s += red[((size_t)r2 * cvb + cx) * RW + k * E::VEC + j];   // fixed order
+        dst[k * (Cp + 1) + cv * E::VEC + j] = s;
+      }
+      if (cv == 0) {
+        float s = 0.f;
+        for (int r2 = 0; r2 < rows; ++r2) s += red[((size_t)r2 * cvb + cx) * RW + MAXC * E::VEC + k];
+        dst[k * (Cp + 1) + Cp] = s;
+      }
     }
   }
 }
@@ -377,8 +353,8 @@ static bool raise_lds(const void* f) {
 
 // ------------------------------------------------------------------------------------------------
 int segk_head_blocks(long P) {
-  long g = (P + HT - 1) / HT;
-  return (int)(g > 256 ? 256 : g);
+  long g = (P + 31) / 32;
+  return (int)(g > 1024 ? 1024 : g);
 }
 int segk_head_part_floats(long P, int Cp) { return segk_head_blocks(P) * MAXC * (Cp + 1); }
 
@@ -400,22 +376,32 @@ int segk_head_fwd_impl(const void* y, const float* w, const float* bias, float* 
   return 0;
 }
 
+template <typename T>
+static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
+                      long P, long HW, int Cp, int C, int ncls, hipStream_t st) {
+  using E = ET<T>;
+  const int cvec = Cp / E::VEC;
+  const int cvb = cvec < 64 ? cvec : 64;
+  const int rows = 256 / cvb, gy = cdiv(cvec, cvb);
+  const int nb = segk_head_blocks(P);
+  const size_t lds = (size_t)rows * cvb * (MAXC * E::VEC + MAXC) * sizeof(float);
+  SEGK_REQUIRE(gy == 1, "head_bwd: at most %d input channels supported", 64 * E::VEC);
+  auto kern = head_bwd_kernel<T>;
+  SEGK_REQUIRE(raise_lds((const void*)kern), "head_bwd: cannot raise dynamic LDS limit");
+  hipLaunchKernelGGL(kern, dim3(nb, gy), dim3(256), lds, st, dlog, (const T*)y, w, (T*)dy, part, P, HW, Cp, C, ncls, cvb, rows);
+  SEGK_CHECK_LAUNCH("head_bwd");
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(ncls * (C + 1), 4)), dim3(256), 0, st, part, nb, Cp, C, ncls, dw, db);
+  SEGK_CHECK_LAUNCH("head_bwd_finalize");
+  return 0;
+}
+
 int segk_head_bwd_impl(const float* dlog, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
                        int B, int H, int W, int Cp, int C, int ncls, int dtype, hipStream_t st) {
   SEGK_REQUIRE(dlog && y && w && dy && part && dw && db && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
   SEGK_REQUIRE(ncls >= 1 && ncls <= MAXC && Cp % 32 == 0 && C > 0 && C <= Cp, "head_bwd: bad channels/classes");
   const long P = (long)B * H * W, HW = (long)H * W;
-  const int nb = segk_head_blocks(P);
-  if (dtype == SEGK_DT_BF16)
-    hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), head_lds<bf16_t>(), st, dlog, (const bf16_t*)y, w, (bf16_t*)dy, part, P, HW, Cp, C, ncls);
-  else {
-    SEGK_REQUIRE(raise_lds((const void*)head_bwd_kernel<float>), "head_bwd: cannot raise dynamic LDS limit");
-    hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(nb), dim3(256), head_lds<float>(), st, dlog, (const float*)y, w, (float*)dy, part, P, HW, Cp, C, ncls);
-  }
-  SEGK_CHECK_LAUNCH("head_bwd");
-  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(ncls * (C + 1), 4)), dim3(256), 0, st, part, nb, Cp, C, ncls, dw, db);
-  SEGK_CHECK_LAUNCH("head_bwd_finalize");
-  return 0;
+  return dtype == SEGK_DT_BF16 ? head_bwd_t<bf16_t>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, st)
+                               : head_bwd_t<float>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, st);
 }
 
 int segk_loss_blocks(long P) {
