@@ -154,6 +154,16 @@ def main():
                          "avg_launch_us": round(avg_s * 1e6, 2),
                          "alg_flops_per_launch": fl, "alg_bytes_per_launch": by,
                          "hbm_frac_same_kernel": round(by / avg_s / HBM_PEAK, 4), "traffic": None})
+        # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE,
+        # gfx950 correction), recorded under profiles/ -- counters cannot be sampled from inside this process
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            fam = {"conv3x3_igemm": "conv3x3", "wgrad3x3": "wgrad3x3"}.get(dom)
+            if fam and args.dtype == "bf16" and B == 32 and S == 256:
+                roofline["traffic"] = pmc["kernels"][fam]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json"
+        except Exception:
+            pass
 
     img_s = world * B * args.steps / dt
     # DoubleConv-scope HBM roofline of SURVEY 8(d): kernels of the 9 DoubleConv blocks only
