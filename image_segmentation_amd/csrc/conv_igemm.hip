@@ -414,6 +414,338 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 }
 
 // ------------------------------------------------------------------------------------------------
+// Software-pipelined 3x3 kernel for the MFMA-bound bf16 layers (channel tiles of 128, K = 9*Cin long).
+//
+// Why it exists (measured with s_memtime stamps and ablation builds on the streaming kernel above at
+// 512->512 @ 32x32, B = 32): the 8 waves of a workgroup run in lock step between barriers, so the
+// streaming kernel's per-step phases never overlap -- 1450 cycles of MFMA, ~450 of global-load issue
+// (64 B/clk/CU), ~380 of ds_write_b128 (~79 B/clk/CU) and ~560 at the barrier, 2900 in all for 1536 cycles
+// of matrix work.  Dropping loads, LDS stores and the barrier from that loop runs it in 98 us instead of
+// 146; the barrier alone costs 24 us, nearly all of it the restart after it: every wave issues its first
+// fragment reads at once and the matrix pipe idles until they return.
+//
+// Structure here:
+//   * ONE phase per step: each pair of MFMAs carries a staging slot (a global load, or an LDS store of
+//     data fetched a step earlier), so the vector-memory and LDS-store pipes run under the matrix pipe;
+//   * weight tiles live in a ring of THREE LDS buffers and are stored two steps ahead of their use, the
+//     next chunk's patch is stored one step before its first use: the first fragments of step s+1 are
+//     therefore complete one barrier early and are read BEFORE the barrier that ends step s, so the
+//     matrix pipe restarts immediately after it;
+//   * the ring keeps running across work units: the next unit's first two weight steps are staged during
+//     the current unit's last two steps (the epilogue tile overlays only the patch buffers and the ring
+//     slot that is dead at that point), so a unit boundary costs one patch store + fragment read.
+// LDS: [W0 | W1 | P0 | P1 | W2], 80-byte pixel pitch: 3 x 30,720 + 2 x 28,160 (8x32 tile) = 148,480 B.
+template <int TWL, bool PRO>
+__global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) {
+  using T = bf16_t;
+  using E = ET<T>;
+  constexpr int WM = 4, WN = 2, MF = 2, NF = 2, NTHR = 512, BM = 256, BN = 128;
+  constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
+  constexpr int ROWP = (PW * PIXB + 255) & ~255;
+  constexpr int PB = PH * ROWP;                    // one patch chunk
+  constexpr int WB = 3 * BN * PIXB;                // one step of weights: 3 taps x 128 rows
+  constexpr int NP = PH * PW * 4, NPL = (NP + NTHR - 1) / NTHR;
+  constexpr int NWL = 3 * BN * 4 / NTHR;           // 16-byte weight pieces per thread and step
+  constexpr int POFF = 2 * WB, W2OFF = POFF + 2 * PB, MAINB = W2OFF + WB;
+  constexpr int NSUB = 6;                          // 3 taps x two k-halves of the 64-byte chunk
+  constexpr int PSLOT = 4;                         // first patch slot (weights use slots 0..NWL-1)
+  static_assert(3 * BN * 4 % NTHR == 0 && NWL <= PSLOT && PSLOT + NPL <= NSUB * MF, "slot plan");
+  auto wring = [](int r) { return r < 2 ? r * WB : W2OFF; };
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int H = a.H, W = a.W;
+
+  // ---- work units: every XCD owns a contiguous range, walked by its workgroups with stride GW
+  const int NT = a.Ntot / BN;
+  const int tpi = a.tiles_x * a.tiles_y;
+  const int U = a.B * tpi * NT;
+  const int xcd = blockIdx.x & 7, upx = (U + 7) >> 3;
+  const int GW = gridDim.x >> 3;
+  int u = xcd * upx + (blockIdx.x >> 3);
+  const int u_end = min(U, (xcd + 1) * upx);
+  if (u >= u_end) return;
+
+  // ---- unit-invariant staging assignment (straight-line: surplus pieces land in a per-thread trash slot)
+  const int trash = MAINB + tid * 16;
+  const int pc = tid & 3;
+  int plds[NPL], prel[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int q = tid + i * NTHR;
+    const int pix = q >> 2;
+    const int py = pix / PW, px = pix - py * PW;
+    plds[i] = (q < NP) ? POFF + py * ROWP + px * PIXB + pc * 16 : trash;
+    prel[i] = (q < NP) ? ((py << 8) | px) : (0x7fff << 8);  // row 32767: outside every image, never valid
+  }
+  int wsrc[NWL], wlds[NWL];
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    const int q = tid + i * NTHR;
+    const int t = q / (BN * 4), r = q - t * (BN * 4);
+    wsrc[i] = t * a.Ntot * 64 + r * 16;              // byte offset from the step's weight base
+    wlds[i] = t * (BN * PIXB) + (r >> 2) * PIXB + (r & 3) * 16;
+  }
+  const int nchA = a.CA / E::CH;
+  const int nchunks = (a.CA + a.CB) / E::CH;
+  const int nsteps = nchunks * 3;
+
+  int laneA[MF], laneB[NF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = (wm * MF + mf) * 32 + lr;
+    laneA[mf] = POFF + (m >> TWL) * ROWP + (m & (TW - 1)) * PIXB + lh * 16;
+  }
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) laneB[nf] = ((wn * NF + nf) * 32 + lr) * PIXB + lh * 16;
+
+  int ub, uy0, ux0, un0, umt;
+  auto decode = [&](int uu, int& mt, int& b, int& y0, int& x0, int& n0) {
+    mt = uu / NT;
+    n0 = (uu - mt * NT) * BN;
+    b = mt / tpi;
+    const int trem = mt - b * tpi;
+    const int tyi = trem / a.tiles_x;
+    y0 = tyi * TH;
+    x0 = (trem - tyi * a.tiles_x) * TW;
+  };
+
+  u32x4 preg[NPL], wreg[NWL];
+  unsigned pvalid = 0;
+  float psc[E::VEC], psh[E::VEC];
+  const T* pl_base = nullptr;        // chunk being fetched: source (at this thread's 16-byte slot), pitch, origin
+  int pl_C = 0, pl_b = 0, pl_y0 = 0, pl_x0 = 0;
+  auto patch_setup = [&](int kc, int b, int y0, int x0) {
+    int coff;
+    if (kc < nchA) { pl_base = (const T*)a.srcA; pl_C = a.CA; coff = kc * E::CH; }
+    else { pl_base = (const T*)a.srcB; pl_C = a.CB; coff = (kc - nchA) * E::CH; }
+    pl_base += coff + pc * E::VEC;
+    pl_b = b; pl_y0 = y0; pl_x0 = x0;
+    pvalid = 0;
+    if (PRO) {
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) {
+        psc[j] = a.scale[coff + pc * E::VEC + j];
+        psh[j] = a.shift[coff + pc * E::VEC + j];
+      }
+    }
+  };
+  auto patch_load_piece = [&](int i) {
+    const int gy = pl_y0 + (prel[i] >> 8) - 1, gx = pl_x0 + (prel[i] & 255) - 1;
+    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int cy = ok ? gy : pl_y0, cx = ok ? gx : pl_x0;   // clamp to the tile origin: always a valid pixel
+    preg[i] = *(const u32x4*)(pl_base + (size_t)((pl_b * H + cy) * W + cx) * pl_C);
+    pvalid |= (ok ? 1u : 0u) << i;
+  };
+  auto patch_store_piece = [&](int i, int pboff, bool live) {
+    u32x4 v = preg[i];
+    if (PRO) {  // BatchNorm(scale, shift) + ReLU of the producer layer, applied on load
+      float f[E::VEC];
+      unpack16<T>(make_uint4(v.x, v.y, v.z, v.w), f);
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
+      const uint4 t = pack16<T>(f);
+      v = (u32x4){t.x, t.y, t.z, t.w};
+    }
+    const bool ok = (pvalid >> i) & 1;   // out-of-image halo pixels are exact zeros (after the transform)
+    v = ok ? v : (u32x4){0u, 0u, 0u, 0u};
+    const int off = (live && plds[i] < MAINB) ? plds[i] + pboff : trash;
+    *(u32x4*)(smem + off) = v;
+  };
+  auto w_base = [&](int s, int n0) -> const char* {   // step s = (chunk s / 3, kernel row s % 3)
+    return (const char*)a.w + ((size_t)(s * 3) * a.Ntot + n0) * 64;
+  };
+  auto load_w = [&](const char* wb) {
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) wreg[i] = *(const u32x4*)(wb + wsrc[i]);
+  };
+  auto store_w = [&](int ring) {
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) *(u32x4*)(smem + wring(ring) + wlds[i]) = wreg[i];
+  };
+
+  f32x16 acc[MF][NF];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+  };
+  uint4 fa[2][MF], fb[2][NF];   // fragment double buffer; [0] is primed before a step begins
+  auto rd = [&](int prow, int wb, int i, uint4 (&A)[MF], uint4 (&Bf)[NF]) {
+    const int t = i >> 1, kk = i & 1;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) A[mf] = *(const uint4*)(smem + prow + laneA[mf] + t * PIXB + kk * 32);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) Bf[nf] = *(const uint4*)(smem + wb + laneB[nf] + t * (BN * PIXB) + kk * 32);
+  };
+
+  // one step (kernel row TG of chunk kc): 6 sub-steps x MF rows of NF MFMAs; row q carries staging slot q
+  auto step = [&](auto TGc, int kc, bool w_live, const char* wnext, bool p_live) {
+    constexpr int TG = decltype(TGc)::value;
+    const int prow = (kc & 1) * PB + TG * ROWP;
+    const int prow_next = (TG < 2) ? prow + ROWP : ((kc + 1) & 1) * PB;
+    constexpr int wb = TG < 2 ? TG * WB : W2OFF, wb_next = (TG + 1) % 3 < 2 ? ((TG + 1) % 3) * WB : W2OFF;
+    constexpr int wb_store = (TG + 2) % 3 < 2 ? ((TG + 2) % 3) * WB : W2OFF;
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i) {
+      if (i + 1 < NSUB) rd(prow, wb, i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+      else rd(prow_next, wb_next, 0, fa[0], fb[0]);          // next step's first fragments, ahead of the barrier
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[i & 1][mf], fb[i & 1][nf], acc[mf][nf]);
+        const int q = i * MF + mf;
+        if (q < NWL) {            // weights of step s+2 (fetched a step ago) -> ring; refill the register for s+3
+          *(u32x4*)(smem + (w_live ? wb_store + wlds[q] : trash)) = wreg[q];
+          wreg[q] = *(const u32x4*)(wnext + wsrc[q]);
+        } else if (q >= PSLOT && q - PSLOT < NPL) {
+          if (TG == 0) patch_load_piece(q - PSLOT);
+          if (TG == 1) patch_store_piece(q - PSLOT, ((kc + 1) & 1) * PB, p_live);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ---- epilogue: as the streaming kernel's, with the output tile overlaying [P0 | P1 | W2]
+  constexpr int OP = BN * E::ES + 16;
+  static_assert(BM * OP + WM * BN * 8 <= MAINB - POFF, "epilogue tile fits behind the two live ring slots");
+  auto epilogue_t = [&](auto FULLc) {
+    constexpr bool FULL = decltype(FULLc)::value;
+    char* const ot = smem + POFF;
+    float* const red = (float*)(ot + BM * OP);
+    const bool do_stats = (a.stats != nullptr);
+    float s1[NF], s2[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      s1[nf] = 0.f;
+      s2[nf] = 0.f;
+      const int n = (wn * NF + nf) * 32 + lr;
+      const float bv = a.bias ? a.bias[un0 + n] : 0.f;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int mb = (wm * MF + mf) * 32 + 4 * lh;
+        char* const obase = ot + mb * OP + n * E::ES;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = (r & 3) + 8 * (r >> 2);
+          const float v = acc[mf][nf][r] + bv;
+          float vs = v;
+          if (!FULL) {
+            const int m = mb + dm;
+            vs = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v : 0.f;
+          }
+          s1[nf] += vs;
+          s2[nf] = fmaf(vs, vs, s2[nf]);
+          *(T*)(obase + dm * OP) = from_float<T>(v);
+        }
+      }
+    }
+    if (do_stats) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        s1[nf] += __shfl_xor(s1[nf], 32);
+        s2[nf] += __shfl_xor(s2[nf], 32);
+        if (lh == 0) {
+          const int n = (wn * NF + nf) * 32 + lr;
+          red[(wm * BN + n) * 2 + 0] = s1[nf];
+          red[(wm * BN + n) * 2 + 1] = s2[nf];
+        }
+      }
+    }
+    __syncthreads();
+    if (do_stats && tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {  // fixed order: bit-stable
+        t1 += red[(w * BN + tid) * 2 + 0];
+        t2 += red[(w * BN + tid) * 2 + 1];
+      }
+      float2* dst = (float2*)a.stats + (size_t)umt * a.Ntot + un0 + tid;
+      *dst = make_float2(t1, t2);
+    }
+    constexpr int CPR = BN * E::ES / 16;   // 16-byte chunks per pixel row of the tile
+    constexpr int NST = BM * CPR / NTHR;
+    const int cc = tid & (CPR - 1);
+    const int n = un0 + cc * E::VEC;
+    T* dbase;
+    size_t pstride;
+    const size_t pix0 = ((size_t)(ub * H + uy0)) * W + ux0;
+    if (n < a.CO1) { dbase = (T*)a.out + pix0 * a.CO1 + n; pstride = a.CO1; }
+    else { dbase = (T*)a.out2 + pix0 * a.CO2 + (n - a.CO1); pstride = a.CO2; }
+    const size_t rstride = (size_t)W * pstride;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int m = (tid + i * NTHR) / CPR;
+      const int ty = m >> TWL, tx = m & (TW - 1);
+      const uint4 v = *(const uint4*)(ot + m * OP + cc * 16);
+      if (FULL || (uy0 + ty < H && ux0 + tx < W)) *(uint4*)(dbase + ty * rstride + tx * pstride) = v;
+    }
+  };
+
+  // ---- first unit: weight steps 0 and 1 and patch chunk 0 into LDS, step 2 in registers
+  decode(u, umt, ub, uy0, ux0, un0);
+  zero_acc();
+  patch_setup(0, ub, uy0, ux0);
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) patch_load_piece(i);
+  load_w(w_base(0, un0));
+  store_w(0);
+  load_w(w_base(1, un0));
+  store_w(1);
+  load_w(w_base(2, un0));
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) patch_store_piece(i, 0, true);
+  __syncthreads();
+  rd(0, 0, 0, fa[0], fb[0]);
+
+  for (;;) {
+    const int un = u + GW;
+    const bool has_next = un < u_end;
+    int nmt = 0, nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
+    if (has_next) decode(un, nmt, nb, ny0, nx0, nn0);
+
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const bool more_chunks = (kc + 1 < nchunks);
+      if (more_chunks) patch_setup(kc + 1, ub, uy0, ux0);
+      else if (has_next) patch_setup(0, nb, ny0, nx0);
+      else patch_setup(0, ub, uy0, ux0);            // nothing follows: harmless in-range loads, never stored
+      auto one = [&](auto TGc) {
+        constexpr int TG = decltype(TGc)::value;
+        const int s = kc * 3 + TG;
+        // weights two steps ahead are stored now, three steps ahead fetched now (the ring runs on into the
+        // next unit); past the last unit both turn into a trash store / a dummy in-range load
+        const bool w_live = (s + 2 < nsteps) || has_next;
+        const char* wnext = (s + 3 < nsteps) ? w_base(s + 3, un0)
+                          : has_next ? w_base(s + 3 - nsteps, nn0) : (const char*)a.w;
+        step(TGc, kc, w_live, wnext, more_chunks);
+        __syncthreads();
+      };
+      one(std::integral_constant<int, 0>{});
+      one(std::integral_constant<int, 1>{});
+      one(std::integral_constant<int, 2>{});
+    }
+    if ((uy0 + TH <= H) && (ux0 + TW <= W)) epilogue_t(std::true_type{});
+    else epilogue_t(std::false_type{});
+    if (!has_next) break;
+    __syncthreads();                 // the epilogue's LDS reads are done: P0/P1/W2 may be rewritten
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) patch_store_piece(i, 0, true);   // next unit's chunk 0 (fetched under the last chunk)
+    zero_acc();
+    u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
+    __syncthreads();
+    rd(0, 0, 0, fa[0], fb[0]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight-stationary variant for the narrow, high-resolution layers (Cin <= 2 chunks, 64 output channels per
 // tile: the 3->64 stem, the 64->64 convs of down1/up4 and the 64->128 concat gradient): these are HBM-bound
 // (K = 9*Cin is tiny), so the structure is built around keeping the memory pipes busy instead of the
@@ -688,6 +1020,33 @@ int launch_ws(ConvArgs a, hipStream_t st) {
   return 0;
 }
 
+template <int TWL, bool PRO>
+int launch_pipe(ConvArgs a, hipStream_t st) {
+  constexpr int BM = 256, BN = 128, NTHR = 512;
+  constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
+  constexpr int ROWP = (PW * PIXB + 255) & ~255;
+  constexpr size_t lds = 3 * (size_t)(3 * BN * PIXB) + 2 * (size_t)PH * ROWP + NTHR * 16;
+  static_assert(lds <= 160 * 1024, "conv3x3_pipe: LDS exceeds 160 KiB");
+  a.twl = TWL;
+  a.tiles_x = cdiv(a.W, TW);
+  a.tiles_y = cdiv(a.H, TH);
+  const int units = a.B * a.tiles_x * a.tiles_y * (a.Ntot / BN);
+  const int per_xcd = (units + 7) / 8;
+  int gw = num_cus() / 8;                                  // one 8-wave workgroup per CU
+  if (gw > per_xcd) gw = per_xcd;
+  a.persistent = 1;
+  auto kern = conv3x3_pipe_kernel<TWL, PRO>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SEGK_FAIL(-3, "conv3x3_pipe: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(8 * gw), dim3(NTHR), lds, st, a);
+  SEGK_CHECK_LAUNCH("conv3x3_pipe");
+  return 0;
+}
+
 template <typename T, int GEO, int TWL, int WM, int WN, int MF, int NF, int PBUF, bool PRO>
 int launch_pro(ConvArgs a, hipStream_t st) {
   using E = ET<T>;
@@ -743,6 +1102,12 @@ int launch_geo(const ConvArgs& a, hipStream_t st) {
     if (segk_conv_use_ws(a.CA + a.CB, a.Ntot, sizeof(T) == 2 ? SEGK_DT_BF16 : SEGK_DT_F32)) {
       if (a.scale) return wide ? launch_ws<T, 5, true>(a, st) : launch_ws<T, 4, true>(a, st);
       return wide ? launch_ws<T, 5, false>(a, st) : launch_ws<T, 4, false>(a, st);
+    }
+  }
+  if constexpr (GEO == 0 && sizeof(T) == 2) {
+    if (unit % 128 == 0) {                         // MFMA-bound bf16 layers: software-pipelined kernel
+      if (a.scale) return wide ? launch_pipe<5, true>(a, st) : launch_pipe<4, true>(a, st);
+      return wide ? launch_pipe<5, false>(a, st) : launch_pipe<4, false>(a, st);
     }
   }
   if (unit % 128 == 0)                             // 256 px x 128 ch, 8 waves

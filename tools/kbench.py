@@ -5,7 +5,10 @@ import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from image_segmentation_amd import ops, _lib
+from image_segmentation_amd import _lib
+if "--lib" in sys.argv:                      # diagnostic builds (ablation / stamp variants of libsegk.so)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+from image_segmentation_amd import ops
 
 LAYERS = [  # name, Cin, Cout, HW   (B = 32)
     ("64->64@256", 64, 64, 256), ("128->64@256", 128, 64, 256), ("64->128@256(dgrad up4)", 64, 128, 256),
@@ -33,6 +36,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--pro", action="store_true")
+    ap.add_argument("--lib", type=str, default="")
     args = ap.parse_args()
     dt = torch.bfloat16
     B = 32
