@@ -414,49 +414,45 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 }
 
 // ------------------------------------------------------------------------------------------------
-// Software-pipelined 3x3 kernel for the MFMA-bound bf16 layers (channel tiles of 128, K = 9*Cin long).
+// Producer / consumer 3x3 kernel for the MFMA-bound bf16 layers (channel tiles of 128, K = 9*Cin long).
 //
-// Why it exists (measured with s_memtime stamps and ablation builds on the streaming kernel above at
-// 512->512 @ 32x32, B = 32): the 8 waves of a workgroup run in lock step between barriers, so the
-// streaming kernel's per-step phases never overlap -- 1450 cycles of MFMA, ~450 of global-load issue
-// (64 B/clk/CU), ~380 of ds_write_b128 (~79 B/clk/CU) and ~560 at the barrier, 2900 in all for 1536 cycles
-// of matrix work.  Dropping loads, LDS stores and the barrier from that loop runs it in 98 us instead of
-// 146; the barrier alone costs 24 us, nearly all of it the restart after it: every wave issues its first
-// fragment reads at once and the matrix pipe idles until they return.
+// Why it exists (s_memtime traces and ablation builds of the symmetric 8-wave kernels at 512->512 @ 32x32,
+// B = 32): with two MFMA waves per SIMD the matrix pipe arbitrates oldest-first, so the two waves of a SIMD
+// run one after the other, and each is an in-order stream in which every staging instruction (global load,
+// ds_write_b128, address arithmetic) behind MFMA k delays MFMA k+1 -- ~2070-2900 cycles per step for 1536
+// cycles of matrix work, whatever the placement of the staging instructions inside the stream.
 //
-// Structure here:
-//   * ONE phase per step: each pair of MFMAs carries a staging slot (a global load, or an LDS store of
-//     data fetched a step earlier), so the vector-memory and LDS-store pipes run under the matrix pipe;
-//   * weight tiles live in a ring of THREE LDS buffers and are stored two steps ahead of their use, the
-//     next chunk's patch is stored one step before its first use: the first fragments of step s+1 are
-//     therefore complete one barrier early and are read BEFORE the barrier that ends step s, so the
-//     matrix pipe restarts immediately after it;
-//   * the ring keeps running across work units: the next unit's first two weight steps are staged during
-//     the current unit's last two steps (the epilogue tile overlays only the patch buffers and the ring
-//     slot that is dead at that point), so a unit boundary costs one patch store + fragment read.
-// LDS: [W0 | W1 | P0 | P1 | W2], 80-byte pixel pitch: 3 x 30,720 + 2 x 28,160 (8x32 tile) = 148,480 B.
+// Structure here: the 8 waves of a workgroup split into
+//   * 4 CONSUMER waves (one per SIMD, raised priority), each owning a 128-pixel x 64-channel tile of the
+//     256 x 128 workgroup tile: their stream is nothing but MFMAs and ds_read_b128 fragment reads (6 reads
+//     per 8 MFMAs, one sub-step ahead; the first fragments of the next step are read BEFORE the barrier
+//     that ends the current one);
+//   * 4 PRODUCER waves (the SIMDs' second waves) that do all staging: weight steps through a ring of three
+//     LDS buffers, stored two steps ahead of their use from registers fetched two steps before that, and
+//     the next chunk's patch (BatchNorm+ReLU prologue and halo zero-fill applied on the way), stored one
+//     step ahead.  Their waits (vmcnt, LDS-store queueing) no longer sit in any MFMA stream.
+// One s_barrier per step joins the two roles.  The weight ring keeps running across work units (the epilogue
+// tile overlays only [P0 | P1 | W2], dead at that point).  LDS: [W0 | W1 | P0 | P1 | W2], 80-byte pitch.
 template <int TWL, bool PRO>
 __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) {
   using T = bf16_t;
   using E = ET<T>;
-  constexpr int WM = 4, WN = 2, MF = 2, NF = 2, NTHR = 512, BM = 256, BN = 128;
+  constexpr int BM = 256, BN = 128, NTHR = 512, NPT = 256;   // NPT: producer threads
+  constexpr int WM = 2, MF = 4, NF = 2;                       // consumer waves: 2 x 2, 128 px x 64 ch each
   constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
   constexpr int ROWP = (PW * PIXB + 255) & ~255;
   constexpr int PB = PH * ROWP;                    // one patch chunk
   constexpr int WB = 3 * BN * PIXB;                // one step of weights: 3 taps x 128 rows
-  constexpr int NP = PH * PW * 4, NPL = (NP + NTHR - 1) / NTHR;
-  constexpr int NWL = 3 * BN * 4 / NTHR;           // 16-byte weight pieces per thread and step
+  constexpr int NP = PH * PW * 4, NPL = (NP + NPT - 1) / NPT;
+  constexpr int NWL = 3 * BN * 4 / NPT;            // 16-byte weight pieces per producer thread and step
   constexpr int POFF = 2 * WB, W2OFF = POFF + 2 * PB, MAINB = W2OFF + WB;
   constexpr int NSUB = 6;                          // 3 taps x two k-halves of the 64-byte chunk
-  constexpr int PSLOT = 4;                         // first patch slot (weights use slots 0..NWL-1)
-  static_assert(3 * BN * 4 % NTHR == 0 && NWL <= PSLOT && PSLOT + NPL <= NSUB * MF, "slot plan");
+  static_assert(3 * BN * 4 % NPT == 0, "weight pieces divide evenly");
   auto wring = [](int r) { return r < 2 ? r * WB : W2OFF; };
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave - wm * WN;
-  const int lr = lane & 31, lh = lane >> 5;
   const int H = a.H, W = a.W;
 
   // ---- work units: every XCD owns a contiguous range, walked by its workgroups with stride GW
@@ -468,41 +464,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   int u = xcd * upx + (blockIdx.x >> 3);
   const int u_end = min(U, (xcd + 1) * upx);
   if (u >= u_end) return;
-
-  // ---- unit-invariant staging assignment (straight-line: surplus pieces land in a per-thread trash slot)
-  const int trash = MAINB + tid * 16;
-  const int pc = tid & 3;
-  int plds[NPL], prel[NPL];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int q = tid + i * NTHR;
-    const int pix = q >> 2;
-    const int py = pix / PW, px = pix - py * PW;
-    plds[i] = (q < NP) ? POFF + py * ROWP + px * PIXB + pc * 16 : trash;
-    prel[i] = (q < NP) ? ((py << 8) | px) : (0x7fff << 8);  // row 32767: outside every image, never valid
-  }
-  int wsrc[NWL], wlds[NWL];
-#pragma unroll
-  for (int i = 0; i < NWL; ++i) {
-    const int q = tid + i * NTHR;
-    const int t = q / (BN * 4), r = q - t * (BN * 4);
-    wsrc[i] = t * a.Ntot * 64 + r * 16;              // byte offset from the step's weight base
-    wlds[i] = t * (BN * PIXB) + (r >> 2) * PIXB + (r & 3) * 16;
-  }
   const int nchA = a.CA / E::CH;
-  const int nchunks = (a.CA + a.CB) / E::CH;
+  const int nchunks = (a.CA + a.CB) / E::CH;       // >= 2 (checked by the launcher)
   const int nsteps = nchunks * 3;
-
-  int laneA[MF], laneB[NF];
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf) {
-    const int m = (wm * MF + mf) * 32 + lr;
-    laneA[mf] = POFF + (m >> TWL) * ROWP + (m & (TW - 1)) * PIXB + lh * 16;
-  }
-#pragma unroll
-  for (int nf = 0; nf < NF; ++nf) laneB[nf] = ((wn * NF + nf) * 32 + lr) * PIXB + lh * 16;
-
-  int ub, uy0, ux0, un0, umt;
   auto decode = [&](int uu, int& mt, int& b, int& y0, int& x0, int& n0) {
     mt = uu / NT;
     n0 = (uu - mt * NT) * BN;
@@ -512,156 +476,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     y0 = tyi * TH;
     x0 = (trem - tyi * a.tiles_x) * TW;
   };
+  int ub, uy0, ux0, un0, umt;
+  decode(u, umt, ub, uy0, ux0, un0);
 
-  u32x4 preg[NPL], wreg[NWL];
-  unsigned pvalid = 0;
-  float psc[E::VEC], psh[E::VEC];
-  const T* pl_base = nullptr;        // chunk being fetched: source (at this thread's 16-byte slot), pitch, origin
-  int pl_C = 0, pl_b = 0, pl_y0 = 0, pl_x0 = 0;
-  auto patch_setup = [&](int kc, int b, int y0, int x0) {
-    int coff;
-    if (kc < nchA) { pl_base = (const T*)a.srcA; pl_C = a.CA; coff = kc * E::CH; }
-    else { pl_base = (const T*)a.srcB; pl_C = a.CB; coff = (kc - nchA) * E::CH; }
-    pl_base += coff + pc * E::VEC;
-    pl_b = b; pl_y0 = y0; pl_x0 = x0;
-    pvalid = 0;
-    if (PRO) {
-#pragma unroll
-      for (int j = 0; j < E::VEC; ++j) {
-        psc[j] = a.scale[coff + pc * E::VEC + j];
-        psh[j] = a.shift[coff + pc * E::VEC + j];
-      }
-    }
-  };
-  auto patch_load_piece = [&](int i) {
-    const int gy = pl_y0 + (prel[i] >> 8) - 1, gx = pl_x0 + (prel[i] & 255) - 1;
-    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const int cy = ok ? gy : pl_y0, cx = ok ? gx : pl_x0;   // clamp to the tile origin: always a valid pixel
-    preg[i] = *(const u32x4*)(pl_base + (size_t)((pl_b * H + cy) * W + cx) * pl_C);
-    pvalid |= (ok ? 1u : 0u) << i;
-  };
-  auto patch_store_piece = [&](int i, int pboff, bool live) {
-    u32x4 v = preg[i];
-    if (PRO) {  // BatchNorm(scale, shift) + ReLU of the producer layer, applied on load
-      float f[E::VEC];
-      unpack16<T>(make_uint4(v.x, v.y, v.z, v.w), f);
-#pragma unroll
-      for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
-      const uint4 t = pack16<T>(f);
-      v = (u32x4){t.x, t.y, t.z, t.w};
-    }
-    const bool ok = (pvalid >> i) & 1;   // out-of-image halo pixels are exact zeros (after the transform)
-    v = ok ? v : (u32x4){0u, 0u, 0u, 0u};
-    const int off = (live && plds[i] < MAINB) ? plds[i] + pboff : trash;
-    *(u32x4*)(smem + off) = v;
-  };
-  auto w_base = [&](int s, int n0) -> const char* {   // step s = (chunk s / 3, kernel row s % 3)
-    return (const char*)a.w + ((size_t)(s * 3) * a.Ntot + n0) * 64;
-  };
-  auto load_w = [&](const char* wb) {
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) wreg[i] = *(const u32x4*)(wb + wsrc[i]);
-  };
-  auto store_w = [&](int ring) {
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) *(u32x4*)(smem + wring(ring) + wlds[i]) = wreg[i];
-  };
-
-  f32x16 acc[MF][NF];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
-  };
-  uint4 fa[2][MF], fb[2][NF];   // fragment double buffer; [0] is primed before a step begins
-  auto rd = [&](int prow, int wb, int i, uint4 (&A)[MF], uint4 (&Bf)[NF]) {
-    const int t = i >> 1, kk = i & 1;
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) A[mf] = *(const uint4*)(smem + prow + laneA[mf] + t * PIXB + kk * 32);
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) Bf[nf] = *(const uint4*)(smem + wb + laneB[nf] + t * (BN * PIXB) + kk * 32);
-  };
-
-  // one step (kernel row TG of chunk kc): 6 sub-steps x MF rows of NF MFMAs; row q carries staging slot q
-  auto step = [&](auto TGc, int kc, bool w_live, const char* wnext, bool p_live) {
-    constexpr int TG = decltype(TGc)::value;
-    const int prow = (kc & 1) * PB + TG * ROWP;
-    const int prow_next = (TG < 2) ? prow + ROWP : ((kc + 1) & 1) * PB;
-    constexpr int wb = TG < 2 ? TG * WB : W2OFF, wb_next = (TG + 1) % 3 < 2 ? ((TG + 1) % 3) * WB : W2OFF;
-    constexpr int wb_store = (TG + 2) % 3 < 2 ? ((TG + 2) % 3) * WB : W2OFF;
-#pragma unroll
-    for (int i = 0; i < NSUB; ++i) {
-      if (i + 1 < NSUB) rd(prow, wb, i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
-      else rd(prow_next, wb_next, 0, fa[0], fb[0]);          // next step's first fragments, ahead of the barrier
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[i & 1][mf], fb[i & 1][nf], acc[mf][nf]);
-        const int q = i * MF + mf;
-        if (q < NWL) {            // weights of step s+2 (fetched a step ago) -> ring; refill the register for s+3
-          *(u32x4*)(smem + (w_live ? wb_store + wlds[q] : trash)) = wreg[q];
-          wreg[q] = *(const u32x4*)(wnext + wsrc[q]);
-        } else if (q >= PSLOT && q - PSLOT < NPL) {
-          if (TG == 0) patch_load_piece(q - PSLOT);
-          if (TG == 1) patch_store_piece(q - PSLOT, ((kc + 1) & 1) * PB, p_live);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-
-  // ---- epilogue: as the streaming kernel's, with the output tile overlaying [P0 | P1 | W2]
+  // ---- the part of the epilogue all 512 threads run: BN-statistics reduction over the consumer rows and
+  // the 16-byte coalesced NHWC stores of the staged tile
   constexpr int OP = BN * E::ES + 16;
   static_assert(BM * OP + WM * BN * 8 <= MAINB - POFF, "epilogue tile fits behind the two live ring slots");
-  auto epilogue_t = [&](auto FULLc) {
+  char* const ot = smem + POFF;
+  float* const red = (float*)(ot + BM * OP);
+  auto store_tile = [&](auto FULLc) {
     constexpr bool FULL = decltype(FULLc)::value;
-    char* const ot = smem + POFF;
-    float* const red = (float*)(ot + BM * OP);
-    const bool do_stats = (a.stats != nullptr);
-    float s1[NF], s2[NF];
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      s1[nf] = 0.f;
-      s2[nf] = 0.f;
-      const int n = (wn * NF + nf) * 32 + lr;
-      const float bv = a.bias ? a.bias[un0 + n] : 0.f;
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const int mb = (wm * MF + mf) * 32 + 4 * lh;
-        char* const obase = ot + mb * OP + n * E::ES;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dm = (r & 3) + 8 * (r >> 2);
-          const float v = acc[mf][nf][r] + bv;
-          float vs = v;
-          if (!FULL) {
-            const int m = mb + dm;
-            vs = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v : 0.f;
-          }
-          s1[nf] += vs;
-          s2[nf] = fmaf(vs, vs, s2[nf]);
-          *(T*)(obase + dm * OP) = from_float<T>(v);
-        }
-      }
-    }
-    if (do_stats) {
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        s1[nf] += __shfl_xor(s1[nf], 32);
-        s2[nf] += __shfl_xor(s2[nf], 32);
-        if (lh == 0) {
-          const int n = (wn * NF + nf) * 32 + lr;
-          red[(wm * BN + n) * 2 + 0] = s1[nf];
-          red[(wm * BN + n) * 2 + 1] = s2[nf];
-        }
-      }
-    }
-    __syncthreads();
-    if (do_stats && tid < BN) {
+    if (a.stats != nullptr && tid < BN) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) {  // fixed order: bit-stable
@@ -690,57 +516,283 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     }
   };
 
-  // ---- first unit: weight steps 0 and 1 and patch chunk 0 into LDS, step 2 in registers
-  decode(u, umt, ub, uy0, ux0, un0);
-  zero_acc();
-  patch_setup(0, ub, uy0, ux0);
+  if (wave >= 4) {
+    // =========================================== PRODUCERS ===========================================
+    // the few staging instructions must never queue behind the partner's MFMA stream: a lower-priority wave's
+    // vector issue is starved by a matrix wave (measured: ~2000 cycles for ~60 instructions)
+    __builtin_amdgcn_s_setprio(3);
+    const int ptid = tid - NPT;
+    const int trash = MAINB + ptid * 16;
+    const int pc = ptid & 3;        // 16-byte slot inside the 64-byte chunk (NPT % 4 == 0: same for every piece)
+    int plds[NPL], prel[NPL];
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) patch_load_piece(i);
-  load_w(w_base(0, un0));
-  store_w(0);
-  load_w(w_base(1, un0));
-  store_w(1);
-  load_w(w_base(2, un0));
+    for (int i = 0; i < NPL; ++i) {
+      const int q = ptid + i * NPT;
+      const int pix = q >> 2;
+      const int py = pix / PW, px = pix - py * PW;
+      plds[i] = (q < NP) ? POFF + py * ROWP + px * PIXB + pc * 16 : trash;
+      prel[i] = (q < NP) ? ((py << 8) | px) : (0x7fff << 8);  // row 32767: outside every image, never valid
+    }
+    unsigned wsrc[NWL];
+    int wlds[NWL];
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) patch_store_piece(i, 0, true);
-  __syncthreads();
-  rd(0, 0, 0, fa[0], fb[0]);
+    for (int i = 0; i < NWL; ++i) {
+      const int q = ptid + i * NPT;
+      const int t = q / (BN * 4), r = q - t * (BN * 4);
+      wsrc[i] = t * a.Ntot * 64 + r * 16;              // byte offset from the step's weight base
+      wlds[i] = t * (BN * PIXB) + (r >> 2) * PIXB + (r & 3) * 16;
+    }
 
+    // ---- patch: per-unit pixel indices and validity, per-chunk source; one register set
+    u32x4 preg[NPL];
+    unsigned pvalid = 0;
+    int plin[NPL];
+    float psc[E::VEC], psh[E::VEC];
+    auto patch_unit = [&](int b, int y0, int x0) {
+      pvalid = 0;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int gy = y0 + (prel[i] >> 8) - 1, gx = x0 + (prel[i] & 255) - 1;
+        const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+        const int cy = ok ? gy : y0, cx = ok ? gx : x0;       // clamp to the tile origin: always a valid pixel
+        plin[i] = (b * H + cy) * W + cx;
+        pvalid |= (ok ? 1u : 0u) << i;
+      }
+    };
+    auto patch_load = [&](int kc) {
+      const T* base;
+      int C, coff;
+      if (kc < nchA) { base = (const T*)a.srcA; C = a.CA; coff = kc * E::CH; }
+      else { base = (const T*)a.srcB; C = a.CB; coff = (kc - nchA) * E::CH; }
+      base += coff + pc * E::VEC;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) preg[i] = *(const u32x4*)(base + (size_t)(unsigned)(plin[i] * C));
+      if (PRO) {
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) {
+          psc[j] = a.scale[coff + pc * E::VEC + j];
+          psh[j] = a.shift[coff + pc * E::VEC + j];
+        }
+      }
+    };
+    auto patch_store = [&](int pboff) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        u32x4 v = preg[i];
+        if (PRO) {  // BatchNorm(scale, shift) + ReLU of the producer layer, applied on load
+          float f[E::VEC];
+          unpack16<T>(make_uint4(v.x, v.y, v.z, v.w), f);
+#pragma unroll
+          for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
+          const uint4 t = pack16<T>(f);
+          v = (u32x4){t.x, t.y, t.z, t.w};
+        }
+        const bool ok = (pvalid >> i) & 1;   // out-of-image halo pixels are exact zeros (after the transform)
+        v = ok ? v : (u32x4){0u, 0u, 0u, 0u};
+        const int off = (plds[i] < MAINB) ? plds[i] + pboff : trash;
+        *(u32x4*)(smem + off) = v;
+      }
+    };
+
+    // ---- weights: step x lives in register set x % 3 from its fetch (during step x-4) to its store
+    // (during step x-2) and in ring slot x % 3 from then until step x has been computed
+    u32x4 wreg[3][NWL];
+    int cu_step = 0, cu_n0 = un0;   // fetch cursor: the next weight step to fetch, (unit, step) walking ahead
+    bool cu_ok = true;              // false past the last unit
+    int nn0 = 0;                    // channel origin of the next unit (set per unit below)
+    bool has_next = false;
+    auto fetch_w = [&](u32x4 (&R)[NWL]) {
+      if (cu_ok) {
+        const char* wb = (const char*)a.w + ((size_t)(cu_step * 3) * a.Ntot + cu_n0) * 64;
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) R[i] = *(const u32x4*)(wb + wsrc[i]);
+        if (++cu_step == nsteps) { cu_step = 0; cu_n0 = nn0; cu_ok = has_next; }
+      }
+    };
+    auto store_w = [&](int ring, const u32x4 (&R)[NWL]) {
+#pragma unroll
+      for (int i = 0; i < NWL; ++i) *(u32x4*)(smem + wring(ring) + wlds[i]) = R[i];
+    };
+
+    // first unit: weight steps 0, 1 and patch chunk 0 into LDS; steps 2, 3 and patch chunk 1 in registers
+    {
+      const int un = u + GW;
+      has_next = un < u_end;
+      int t0, t1, t2, t3;
+      if (has_next) decode(un, t0, t1, t2, t3, nn0);
+    }
+    patch_unit(ub, uy0, ux0);
+    patch_load(0);
+    fetch_w(wreg[0]);
+    fetch_w(wreg[1]);
+    store_w(0, wreg[0]);
+    store_w(1, wreg[1]);
+    patch_store(0);
+    fetch_w(wreg[2]);
+    fetch_w(wreg[0]);
+    patch_load(1);
+    __syncthreads();                                   // B0
+    for (;;) {
+      const int un = u + GW;
+      has_next = un < u_end;
+      int nmt = 0, nb = 0, ny0 = 0, nx0 = 0;
+      if (has_next) decode(un, nmt, nb, ny0, nx0, nn0);
+      for (int kc = 0; kc < nchunks; ++kc) {
+        // step TG0: ring slot 2 <- weights of step s+2; fetch step s+4
+        store_w(2, wreg[2]);
+        fetch_w(wreg[1]);
+        __syncthreads();
+        // step TG1: the next chunk's patch, ring slot 0
+        if (kc + 1 < nchunks) patch_store(((kc + 1) & 1) * PB);
+        store_w(0, wreg[0]);
+        fetch_w(wreg[2]);
+        __syncthreads();
+        // step TG2: ring slot 1; fetch the patch two chunks ahead (the next unit's chunk 0 from the
+        // second-to-last chunk; the last chunk fetches nothing: its registers are stored after the epilogue)
+        store_w(1, wreg[1]);
+        fetch_w(wreg[0]);
+        if (kc + 2 < nchunks) patch_load(kc + 2);
+        else if (kc + 2 == nchunks && has_next) { patch_unit(nb, ny0, nx0); patch_load(0); }
+        __syncthreads();
+      }
+      __syncthreads();                                 // E1: the consumers have staged the output tile
+      if ((uy0 + TH <= H) && (ux0 + TW <= W)) store_tile(std::true_type{});
+      else store_tile(std::false_type{});
+      if (!has_next) break;
+      __syncthreads();                                 // E2: tile consumed, [P0 | P1 | W2] may be rewritten
+      patch_store(0);                                  // next unit's chunk 0
+      patch_load(1);                                   // and its chunk 1, stored during its step 1
+      u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
+      __syncthreads();                                 // E3
+    }
+    return;
+  }
+
+  // ============================================= CONSUMERS =============================================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  int laneA[MF], laneB[NF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = (wm * MF + mf) * 32 + lr;
+    laneA[mf] = POFF + (m >> TWL) * ROWP + (m & (TW - 1)) * PIXB + lh * 16;
+  }
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) laneB[nf] = ((wn * NF + nf) * 32 + lr) * PIXB + lh * 16;
+
+  f32x16 acc[MF][NF];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+  };
+  uint4 fa[2][MF], fb[2][NF];   // fragment double buffer; [0] is primed before a step begins
+  auto rd = [&](int prow, int wb, int i, uint4 (&A)[MF], uint4 (&Bf)[NF]) {
+    const int t = i >> 1, kk = i & 1;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) A[mf] = *(const uint4*)(smem + prow + laneA[mf] + t * PIXB + kk * 32);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) Bf[nf] = *(const uint4*)(smem + wb + laneB[nf] + t * (BN * PIXB) + kk * 32);
+  };
+  // one step (kernel row TG of chunk kc): 6 sub-steps of 8 MFMAs, fragments read one sub-step (256 matrix
+  // cycles) ahead; the last sub-step reads the next step's first fragments
+  auto step = [&](auto TGc, int kc) {
+    constexpr int TG = decltype(TGc)::value;
+    const int prow = (kc & 1) * PB + TG * ROWP;
+    const int prow_next = (TG < 2) ? prow + ROWP : ((kc + 1) & 1) * PB;
+    constexpr int wb = TG < 2 ? TG * WB : W2OFF, wb_next = (TG + 1) % 3 < 2 ? ((TG + 1) % 3) * WB : W2OFF;
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i) {
+      if (i + 1 < NSUB) rd(prow, wb, i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+      else rd(prow_next, wb_next, 0, fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[i & 1][mf], fb[i & 1][nf], acc[mf][nf]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto stage_tile = [&](bool full) {   // bias, BN partial sums from the fp32 accumulators, tile -> LDS
+    if (a.bias) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const float bv = a.bias[un0 + (wn * NF + nf) * 32 + lr];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mf][nf][r] += bv;
+      }
+    }
+    if (!full) {   // rare: pixels past the image edge must not enter the statistics (they are never stored)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MF + mf) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+          const bool in = (uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) acc[mf][nf][r] = in ? acc[mf][nf][r] : 0.f;
+        }
+    }
+    const bool do_stats = (a.stats != nullptr);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      float s1 = 0.f, s2 = 0.f;
+      const int n = (wn * NF + nf) * 32 + lr;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int mb = (wm * MF + mf) * 32 + 4 * lh;
+        char* const obase = ot + mb * OP + n * E::ES;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = (r & 3) + 8 * (r >> 2);
+          const float v = acc[mf][nf][r];
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+          *(T*)(obase + dm * OP) = from_float<T>(v);
+        }
+      }
+      if (do_stats) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0) {
+          red[(wm * BN + n) * 2 + 0] = s1;
+          red[(wm * BN + n) * 2 + 1] = s2;
+        }
+      }
+    }
+  };
+
+  zero_acc();
+  __syncthreads();                                     // B0
+  rd(0, 0, 0, fa[0], fb[0]);
   for (;;) {
     const int un = u + GW;
     const bool has_next = un < u_end;
     int nmt = 0, nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
     if (has_next) decode(un, nmt, nb, ny0, nx0, nn0);
-
     for (int kc = 0; kc < nchunks; ++kc) {
-      const bool more_chunks = (kc + 1 < nchunks);
-      if (more_chunks) patch_setup(kc + 1, ub, uy0, ux0);
-      else if (has_next) patch_setup(0, nb, ny0, nx0);
-      else patch_setup(0, ub, uy0, ux0);            // nothing follows: harmless in-range loads, never stored
-      auto one = [&](auto TGc) {
-        constexpr int TG = decltype(TGc)::value;
-        const int s = kc * 3 + TG;
-        // weights two steps ahead are stored now, three steps ahead fetched now (the ring runs on into the
-        // next unit); past the last unit both turn into a trash store / a dummy in-range load
-        const bool w_live = (s + 2 < nsteps) || has_next;
-        const char* wnext = (s + 3 < nsteps) ? w_base(s + 3, un0)
-                          : has_next ? w_base(s + 3 - nsteps, nn0) : (const char*)a.w;
-        step(TGc, kc, w_live, wnext, more_chunks);
-        __syncthreads();
-      };
-      one(std::integral_constant<int, 0>{});
-      one(std::integral_constant<int, 1>{});
-      one(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 0>{}, kc);
+      __syncthreads();
+      step(std::integral_constant<int, 1>{}, kc);
+      __syncthreads();
+      step(std::integral_constant<int, 2>{}, kc);
+      __syncthreads();
     }
-    if ((uy0 + TH <= H) && (ux0 + TW <= W)) epilogue_t(std::true_type{});
-    else epilogue_t(std::false_type{});
+    const bool full = (uy0 + TH <= H) && (ux0 + TW <= W);
+    stage_tile(full);
+    __syncthreads();                                   // E1
+    if (full) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
     if (!has_next) break;
-    __syncthreads();                 // the epilogue's LDS reads are done: P0/P1/W2 may be rewritten
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) patch_store_piece(i, 0, true);   // next unit's chunk 0 (fetched under the last chunk)
     zero_acc();
+    __syncthreads();                                   // E2
     u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
-    __syncthreads();
+    __syncthreads();                                   // E3: the next unit's chunk 0 is in P0
     rd(0, 0, 0, fa[0], fb[0]);
   }
 }
@@ -1025,7 +1077,7 @@ int launch_pipe(ConvArgs a, hipStream_t st) {
   constexpr int BM = 256, BN = 128, NTHR = 512;
   constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
   constexpr int ROWP = (PW * PIXB + 255) & ~255;
-  constexpr size_t lds = 3 * (size_t)(3 * BN * PIXB) + 2 * (size_t)PH * ROWP + NTHR * 16;
+  constexpr size_t lds = 3 * (size_t)(3 * BN * PIXB) + 2 * (size_t)PH * ROWP + (NTHR / 2) * 16;   // + producers' trash slots
   static_assert(lds <= 160 * 1024, "conv3x3_pipe: LDS exceeds 160 KiB");
   a.twl = TWL;
   a.tiles_x = cdiv(a.W, TW);
@@ -1105,7 +1157,7 @@ int launch_geo(const ConvArgs& a, hipStream_t st) {
     }
   }
   if constexpr (GEO == 0 && sizeof(T) == 2) {
-    if (unit % 128 == 0) {                         // MFMA-bound bf16 layers: software-pipelined kernel
+    if (unit % 128 == 0 && a.CA + a.CB >= 64) {    // MFMA-bound bf16 layers: producer/consumer kernel
       if (a.scale) return wide ? launch_pipe<5, true>(a, st) : launch_pipe<4, true>(a, st);
       return wide ? launch_pipe<5, false>(a, st) : launch_pipe<4, false>(a, st);
     }
