@@ -80,6 +80,35 @@ template <typename T> __device__ __forceinline__ float to_float(T v);
 template <> __device__ __forceinline__ float to_float<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_float<bf16_t>(bf16_t v) { return (float)v; }
 
+// Conv epilogue helper: the 16 fp32 results one lane holds of a 32x32 accumulator fragment (one output channel,
+// pixel rows (r & 3) + 8 (r >> 2) of the fragment) -> running per-channel (sum, sum of squares) for
+// training-mode BatchNorm, and stores into the [pixel][channel] LDS staging tile (row pitch OP bytes).
+// Packed fp32 math (v_pk_add_f32 / v_pk_fma_f32) and paired bf16 conversion halve the VALU count; the
+// pairwise summation order is fixed, so the statistics stay bit-stable run to run.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void stage_frag(const float (&v)[16], char* obase, int OP, float& s1, float& s2) {
+  f32x2_t p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const int dm = (r & 3) + 8 * (r >> 2);          // r even: rows dm and dm + 1
+    const f32x2_t x = {v[r], v[r + 1]};
+    p1 += x;
+    p2 = __builtin_elementwise_fma(x, x, p2);
+    if constexpr (sizeof(T) == 2) {
+      uint32_t pk;   // ONE conversion for the pair (the compiler otherwise converts each half on its own)
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x.x), "v"(x.y));
+      *(uint16_t*)(obase + dm * OP) = (uint16_t)(pk & 0xffffu);
+      *(uint16_t*)(obase + (dm + 1) * OP) = (uint16_t)(pk >> 16);
+    } else {
+      *(float*)(obase + dm * OP) = x.x;
+      *(float*)(obase + (dm + 1) * OP) = x.y;
+    }
+  }
+  s1 += p1.x + p1.y;
+  s2 += p2.x + p2.y;
+}
+
 // XCD-aware block remap: blocks b and b+8 share an XCD (observed round-robin dispatch; speed only).
 // Gives each XCD a contiguous range of logical ids so neighbouring tiles share one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

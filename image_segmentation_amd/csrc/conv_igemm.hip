@@ -292,19 +292,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
       for (int mf = 0; mf < MF; ++mf) {
         const int mb = (wm * MF + mf) * 32 + 4 * lh;
         char* const obase = ot + mb * OP + n * E::ES;
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int dm = (r & 3) + 8 * (r >> 2);
-          const float v = acc[mf][nf][r] + bv;
-          float vs = v;
-          if (!FULL) {
-            const int m = mb + dm;
-            vs = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v : 0.f;
+          v[r] = acc[mf][nf][r] + bv;
+          if (!FULL) {   // pixels past the image edge are never stored and must not enter the statistics
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            v[r] = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v[r] : 0.f;
           }
-          s1[nf] += vs;
-          s2[nf] = fmaf(vs, vs, s2[nf]);
-          *(T*)(obase + dm * OP) = from_float<T>(v);
         }
+        stage_frag<T>(v, obase, OP, s1[nf], s2[nf]);
       }
     }
     if (do_stats) {
@@ -747,14 +744,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       for (int mf = 0; mf < MF; ++mf) {
         const int mb = (wm * MF + mf) * 32 + 4 * lh;
         char* const obase = ot + mb * OP + n * E::ES;
+        float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dm = (r & 3) + 8 * (r >> 2);
-          const float v = acc[mf][nf][r];
-          s1 += v;
-          s2 = fmaf(v, v, s2);
-          *(T*)(obase + dm * OP) = from_float<T>(v);
-        }
+        for (int r = 0; r < 16; ++r) v[r] = acc[mf][nf][r];
+        stage_frag<T>(v, obase, OP, s1, s2);
       }
       if (do_stats) {
         s1 += __shfl_xor(s1, 32);
@@ -941,19 +934,16 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvArgs a) {
     for (int mf = 0; mf < MF; ++mf) {
       const int mb = (wm * MF + mf) * 32 + 4 * lh;
       char* const obase = ot + mb * OP + n * E::ES;
+      float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int dm = (r & 3) + 8 * (r >> 2);
-        const float v = acc[mf][r] + bv;
-        float vs = v;
+        v[r] = acc[mf][r] + bv;
         if (!FULL) {
-          const int m = mb + dm;
-          vs = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v : 0.f;
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          v[r] = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v[r] : 0.f;
         }
-        s1 += vs;
-        s2 = fmaf(vs, vs, s2);
-        *(T*)(obase + dm * OP) = from_float<T>(v);
       }
+      stage_frag<T>(v, obase, OP, s1, s2);
     }
     if (do_stats) {
       s1 += __shfl_xor(s1, 32);
