@@ -336,7 +336,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     T* dbase;
     size_t pstride, rstride;       // elements per pixel step in x / per row step in y
     if (a.shuffle) {               // ConvTranspose2d(k=2,s=2): N = (a*2+c)*Cout + co -> pixel (2y+a, 2x+c)
-      const int tq = un0 / a.CO1, co = n - tq * a.CO1;
+      const int tq = n / a.CO1, co = n - tq * a.CO1;   // per thread: a channel tile may span several taps
       dbase = (T*)a.out + (((size_t)(ub * 2 * H + 2 * uy0 + (tq >> 1))) * (2 * W) + 2 * ux0 + (tq & 1)) * a.CO1 + co;
       pstride = 2 * (size_t)a.CO1;
       rstride = 4 * (size_t)W * a.CO1;
@@ -1136,8 +1136,8 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 template <typename T, int GEO>
 int launch_geo(const ConvArgs& a, hipStream_t st) {
-  // BN must divide N; with the pixel-shuffle store a channel tile must not straddle two taps.
-  const int unit = a.shuffle ? a.CO1 : a.Ntot;
+  // BN must divide N (with the pixel-shuffle store a tile may span taps: each thread derives its own tap)
+  const int unit = a.Ntot;
   const bool wide = a.W > 16;                      // 8x32 tiles unless the image is at most 16 wide
   if constexpr (GEO == 0 && sizeof(T) == 2) {
     // narrow high-resolution layers: weight-stationary streaming kernel (64-channel tiles)
@@ -1151,6 +1151,12 @@ int launch_geo(const ConvArgs& a, hipStream_t st) {
       if (a.scale) return wide ? launch_pipe<5, true>(a, st) : launch_pipe<4, true>(a, st);
       return wide ? launch_pipe<5, false>(a, st) : launch_pipe<4, false>(a, st);
     }
+  }
+  if constexpr (GEO == 1 && sizeof(T) == 2) {
+    // 1x1 / ConvTranspose GEMMs have a short K (Cin) and are bound by their output epilogue: 128-pixel tiles on
+    // 4-wave workgroups, two per CU, so one workgroup's epilogue overlaps the other's loads and MFMAs
+    if (unit % 128 == 0) return launch_cfg<T, GEO, 4, 2, 2, 2, 2, 2>(a, st);
+    if (unit % 64 == 0) return launch_cfg<T, GEO, 4, 2, 2, 2, 1, 2>(a, st);
   }
   if (unit % 128 == 0)                             // 256 px x 128 ch, 8 waves
     return wide ? launch_cfg<T, GEO, 5, 4, 2, 2, 2, 2>(a, st) : launch_cfg<T, GEO, 4, 4, 2, 2, 2, 2>(a, st);

@@ -65,5 +65,31 @@ def main():
             print(f"wgrad {name:26s} {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {by/us/1e3:7.1f} GB/s(alg)")
 
 
+def convt():
+    """ConvTranspose2d(k=2,s=2) layers of the U-Net up path: forward, data gradient, weight gradient."""
+    dt = torch.bfloat16
+    B = 32
+    for cin, cout, hw in [(1024, 512, 16), (512, 256, 32), (256, 128, 64), (128, 64, 128)]:
+        x = torch.randn((B, hw, hw, cin), device="cuda").to(dt)
+        dy = torch.randn((B, 2 * hw, 2 * hw, cout), device="cuda").to(dt)
+        w = torch.randn((cin, cout, 2, 2), device="cuda") / cin ** 0.5
+        wf, wd = ops.pack_convt(w, dt, 0), ops.pack_convt(w, dt, 1)
+        out = torch.empty_like(dy)
+        dx = torch.empty_like(x)
+        by = B * hw * hw * (cin + 4 * cout) * 2
+        fl = 2.0 * B * hw * hw * cin * 4 * cout
+        s = torch.cuda.current_stream().cuda_stream
+        t1 = timeit(lambda: _lib.call("segk_convt2x2_fwd", x.data_ptr(), wf.data_ptr(), 0, out.data_ptr(), B, hw, hw, cin,
+                                      cout, 1, s), 20)
+        t2 = timeit(lambda: _lib.call("segk_convt2x2_dgrad", dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, hw, hw, cin,
+                                      cout, 1, s), 20)
+        t3 = timeit(lambda: ops.wgrad(x.data_ptr(), cin, dy.data_ptr(), cout, 0, 0, B, hw, hw, 2, dt, "cuda"), 20)
+        for nm, t in (("fwd", t1), ("dgrad", t2), ("wgrad", t3)):
+            print(f"convt {nm:5s} {cin}->{cout}@{hw}  {t:8.1f} us  {fl/t/1e6:7.1f} TF/s  {by/t/1e3:7.1f} GB/s(alg)")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "convt":
+        convt()
+        sys.exit(0)
     main()
