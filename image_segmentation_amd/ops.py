@@ -439,6 +439,45 @@ class MaxPoolFn(torch.autograd.Function):
         return act_view(dx, C), None
 
 
+class MaxPoolSkipFn(torch.autograd.Function):
+    """MaxPool2d(2,2) of a tensor that is ALSO consumed as a skip connection (unet.py:96-103: x1..x4 feed both the
+    next Down block and an Up block).  Returns (pooled, skip) where skip aliases the input; the backward then
+    receives both gradients and routes the pooled one INTO the skip gradient in one kernel (accumulate mode),
+    instead of a pooling-backward pass plus a separate elementwise add over the full-resolution tensor."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _require_cuda(x, "MaxPool2d")
+        x_t, px, Cp = _raw(x, dtype)
+        B, C, H, W = x.shape
+        y = torch.empty((B, H // 2, W // 2, Cp), dtype=dtype, device=x.device)
+        with _span("maxpool_fwd", 0.0, 1.25 * B * H * W * C * _es(dtype)):
+            _lib.call("segk_maxpool2x2_fwd", px, y.data_ptr(), B, H, W, Cp, _DT[dtype], _stream())
+        ctx.save_for_backward(x_t)
+        ctx.dtype = dtype
+        return act_view(y, C), x_t.view_as(x_t)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        (x_t,) = ctx.saved_tensors
+        dtype = ctx.dtype
+        B, C, H, W = x_t.shape
+        px, Cp = act_info(x_t, dtype)
+        if dy is None:
+            return dskip, None
+        dy_t, pdy, _ = _raw(dy, dtype)
+        if dskip is None:
+            dx = act_view(torch.empty((B, H, W, Cp), dtype=dtype, device=x_t.device), C)
+            pdx, acc, nbytes = dx.data_ptr(), 0, 2.25
+        else:
+            # the skip gradient arrives as an act tensor (logical NCHW view of an NHWC buffer): add into its storage
+            dx, pdx, _ = _raw(dskip, dtype)
+            acc, nbytes = 1, 3.25
+        with _span("maxpool_bwd", 0.0, nbytes * B * H * W * C * _es(dtype)):
+            _lib.call("segk_maxpool2x2_bwd", px, pdy, pdx, B, H, W, Cp, acc, _DT[dtype], _stream())
+        return dx, None
+
+
 class ConvT2x2Fn(torch.autograd.Function):
     """nn.ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) -- reference unet/unet.py:59, clip/clipunet.py:83.
     Non-overlapping, so forward is one GEMM [P x Cin].[Cin x 4Cout] with a pixel-shuffle store."""

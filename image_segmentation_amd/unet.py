@@ -54,9 +54,14 @@ class Down(nn.Module):
             DoubleConvReLU(din, dout),
         )
 
-    def forward(self, x):
+    def forward(self, x, return_skip=False):
+        """return_skip: also return an alias of x to be used as the skip connection, so that the pooling backward
+        adds its routed gradient straight into the skip gradient (one kernel instead of pool-backward + add)."""
         dc = self.maxpool_doubleConv[1]
         dtype = dc.compute_dtype or ops.get_compute_dtype()
+        if return_skip:
+            p, skip = ops.MaxPoolSkipFn.apply(x, dtype)
+            return dc(p), skip
         return dc(ops.MaxPoolFn.apply(x, dtype))
 
 
@@ -101,14 +106,14 @@ class unet(_FusedBase):
 
     def forward(self, x):
         x1 = self.down1(x)
-        x2 = self.down2(x1)
-        x3 = self.down3(x2)
-        x4 = self.down4(x3)
-        x5 = self.down5(x4)
+        x2, s1 = self.down2(x1, return_skip=True)     # s1..s4 alias x1..x4 (the skip connections, unet.py:96-103)
+        x3, s2 = self.down3(x2, return_skip=True)
+        x4, s3 = self.down4(x3, return_skip=True)
+        x5, s4 = self.down5(x4, return_skip=True)
 
-        x = self.up1(x4, x5)
-        x = self.up2(x3, x)
-        x = self.up3(x2, x)
-        x = self.up4(x1, x)
+        x = self.up1(s4, x5)
+        x = self.up2(s3, x)
+        x = self.up3(s2, x)
+        x = self.up4(s1, x)
 
         return ops.HeadFn.apply(self, x, self.output.weight, self.output.bias)
