@@ -9,6 +9,7 @@
 //          over N,H,W; dc = (2I+s)/clip(Sp+Sg+s, 1e-8); (weighted) mean over non-ignored classes; loss = -mean
 //   combined = dice_weight * dice + ce_weight * ce   (weighted_loss.py:165)
 // Metric: utils/MetricsHistory.py:65-75 (argmax -> first maximum, per-class TP/FP/FN/TN).
+#include <type_traits>
 #include "common.hpp"
 #include "segk_internal.h"
 #include "../../include/segk.h"
@@ -20,7 +21,8 @@ constexpr int HCH = 64;    // channels staged per pass
 
 // ------------------------------------------------------------------------------------------------
 // logits[b][k][y][x] = bias[k] + sum_c y[p][c] * Wt[k][c]
-template <typename T>
+// NC = compiled class count (>= ncls): the per-class loops are unrolled to it, not to MAXC
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ logits,
                                                        long P, long HW, int Cp, int C, int ncls) {
@@ -30,9 +32,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
   __shared__ float ws[MAXC * HCH];
   const int tid = threadIdx.x;
   for (long p0 = (long)blockIdx.x * HT; p0 < P; p0 += (long)gridDim.x * HT) {
-    float acc[MAXC];
+    float acc[NC];
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) acc[k] = (k < ncls) ? bias[k] : 0.f;
+    for (int k = 0; k < NC; ++k) acc[k] = (k < ncls) ? bias[k] : 0.f;
     for (int c0 = 0; c0 < Cp; c0 += HCH) {
       __syncthreads();
       constexpr int VPR = HCH / E::VEC;  // 16-byte vectors per pixel row of this pass
@@ -54,14 +56,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
 #pragma unroll
         for (int j = 0; j < E::VEC; ++j)
 #pragma unroll
-          for (int k = 0; k < MAXC; ++k) acc[k] = fmaf(f[j], ws[k * HCH + v * E::VEC + j], acc[k]);
+          for (int k = 0; k < NC; ++k) acc[k] = fmaf(f[j], ws[k * HCH + v * E::VEC + j], acc[k]);
       }
     }
     const long p = p0 + tid;
     if (p < P) {
       const long b = p / HW, r = p - b * HW;
 #pragma unroll
-      for (int k = 0; k < MAXC; ++k)
+      for (int k = 0; k < NC; ++k)
         if (k < ncls) logits[(b * ncls + k) * HW + r] = acc[k];
     }
   }
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
 // dy[p][c] = sum_k dl[p][k] * W[k][c];  partial dW[k][c] = sum_p dl[p][k]*y[p][c], db[k] = sum_p dl[p][k].
 // Pure streaming: a thread owns one 16-byte channel vector (its weights W[k][c..c+VEC) and its dW partials
 // live in registers) and walks pixels; a row of threads covers whole contiguous pixel rows of y / dy.
-template <typename T>
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlog, const T* __restrict__ y,
                                                        const float* __restrict__ w, T* __restrict__ dy,
                                                        float* __restrict__ part, long P, long HW, int Cp, int C,
@@ -82,9 +84,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   const int cx = threadIdx.x % cvb, ry = threadIdx.x / cvb;
   const int cv = blockIdx.y * cvb + cx;
   const bool active = cv < Cp / E::VEC && ry < rows;
-  float wr[MAXC][E::VEC], aw[MAXC][E::VEC], ab[MAXC];
+  float wr[NC][E::VEC], aw[NC][E::VEC], ab[NC];
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k) {
+  for (int k = 0; k < NC; ++k) {
     ab[k] = 0.f;
 #pragma unroll
     for (int j = 0; j < E::VEC; ++j) {
@@ -96,15 +98,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (active) {
     for (long p = (long)blockIdx.x * rows + ry; p < P; p += (long)gridDim.x * rows) {
       const long b = p / HW, r = p - b * HW;
-      float dl[MAXC];
+      float dl[NC];
 #pragma unroll
-      for (int k = 0; k < MAXC; ++k) dl[k] = (k < ncls) ? dlog[(b * ncls + k) * HW + r] : 0.f;
+      for (int k = 0; k < NC; ++k) dl[k] = (k < ncls) ? dlog[(b * ncls + k) * HW + r] : 0.f;
       float f[E::VEC], o[E::VEC];
       unpack16<T>(*(const uint4*)(y + (size_t)p * Cp + cv * E::VEC), f);
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) o[j] = 0.f;
 #pragma unroll
-      for (int k = 0; k < MAXC; ++k) {
+      for (int k = 0; k < NC; ++k) {
         ab[k] += dl[k];
 #pragma unroll
         for (int j = 0; j < E::VEC; ++j) {
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (ry < rows) {
     float* q = red + ((size_t)ry * cvb + cx) * RW;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
+    for (int k = 0; k < NC; ++k) {
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) q[k * E::VEC + j] = aw[k][j];
       q[MAXC * E::VEC + k] = ab[k];
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     // part layout: [block][MAXC][Cp + 1]  (last column = bias gradient, written by channel vector 0)
     float* dst = part + (size_t)blockIdx.x * MAXC * (Cp + 1);
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
+    for (int k = 0; k < NC; ++k) {
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) {
         float s = 0.f;
@@ -366,12 +368,23 @@ int segk_head_fwd_impl(const void* y, const float* w, const float* bias, float* 
   const long P = (long)B * H * W, HW = (long)H * W;
   long g = (P + HT - 1) / HT;
   if (g > 4096) g = 4096;
-  if (dtype == SEGK_DT_BF16)
-    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3((int)g), dim3(256), head_lds<bf16_t>(), st, (const bf16_t*)y, w, bias, logits, P, HW, Cp, C, ncls);
-  else {
-    SEGK_REQUIRE(raise_lds((const void*)head_fwd_kernel<float>), "head_fwd: cannot raise dynamic LDS limit");
-    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((int)g), dim3(256), head_lds<float>(), st, (const float*)y, w, bias, logits, P, HW, Cp, C, ncls);
-  }
+  // kernels are compiled for 2, 3, 4 and MAXC classes: the smallest that holds ncls
+  auto launch = [&](auto Tc, auto NCc) {
+    using T = decltype(Tc);
+    constexpr int NC = decltype(NCc)::value;
+    auto kern = head_fwd_kernel<T, NC>;
+    if (!raise_lds((const void*)kern)) return false;
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(256), head_lds<T>(), st, (const T*)y, w, bias, logits, P, HW, Cp, C, ncls);
+    return true;
+  };
+  auto by_nc = [&](auto Tc) {
+    if (ncls <= 2) return launch(Tc, std::integral_constant<int, 2>{});
+    if (ncls == 3) return launch(Tc, std::integral_constant<int, 3>{});
+    if (ncls == 4) return launch(Tc, std::integral_constant<int, 4>{});
+    return launch(Tc, std::integral_constant<int, MAXC>{});
+  };
+  const bool ok = dtype == SEGK_DT_BF16 ? by_nc(bf16_t{}) : by_nc(float{});
+  SEGK_REQUIRE(ok, "head_fwd: cannot raise dynamic LDS limit");
   SEGK_CHECK_LAUNCH("head_fwd");
   return 0;
 }
@@ -386,9 +399,18 @@ static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy
   const int nb = segk_head_blocks(P);
   const size_t lds = (size_t)rows * cvb * (MAXC * E::VEC + MAXC) * sizeof(float);
   SEGK_REQUIRE(gy == 1, "head_bwd: at most %d input channels supported", 64 * E::VEC);
-  auto kern = head_bwd_kernel<T>;
-  SEGK_REQUIRE(raise_lds((const void*)kern), "head_bwd: cannot raise dynamic LDS limit");
-  hipLaunchKernelGGL(kern, dim3(nb, gy), dim3(256), lds, st, dlog, (const T*)y, w, (T*)dy, part, P, HW, Cp, C, ncls, cvb, rows);
+  auto launch = [&](auto NCc) {
+    constexpr int NC = decltype(NCc)::value;
+    auto kern = head_bwd_kernel<T, NC>;
+    if (!raise_lds((const void*)kern)) return false;
+    hipLaunchKernelGGL(kern, dim3(nb, gy), dim3(256), lds, st, dlog, (const T*)y, w, (T*)dy, part, P, HW, Cp, C, ncls, cvb, rows);
+    return true;
+  };
+  const bool ok = ncls <= 2 ? launch(std::integral_constant<int, 2>{})
+                : ncls == 3 ? launch(std::integral_constant<int, 3>{})
+                : ncls == 4 ? launch(std::integral_constant<int, 4>{})
+                            : launch(std::integral_constant<int, MAXC>{});
+  SEGK_REQUIRE(ok, "head_bwd: cannot raise dynamic LDS limit");
   SEGK_CHECK_LAUNCH("head_bwd");
   hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(ncls * (C + 1), 4)), dim3(256), 0, st, part, nb, Cp, C, ncls, dw, db);
   SEGK_CHECK_LAUNCH("head_bwd_finalize");

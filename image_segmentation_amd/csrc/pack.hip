@@ -7,17 +7,27 @@
 
 namespace {
 
+// one thread per (pixel, 16-byte channel group): plane reads are coalesced across consecutive pixels, the store is
+// one 16-byte piece of the pixel's NHWC row
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W,
                                     int Cp) {
-  const long total = (long)B * H * W * Cp;
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = Cp / VEC;
+  const long hw = (long)H * W;
+  const long total = (long)B * hw * CV;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % Cp);
-    const long p = i / Cp;
-    const long hw = (long)H * W;
+    const int g = (int)(i % CV);
+    const long p = i / CV;
     const int b = (int)(p / hw);
     const long r = p - (long)b * hw;
-    dst[i] = from_float<T>(c < C ? src[((long)b * C + c) * hw + r] : 0.f);
+    float f[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = g * VEC + j;
+      f[j] = c < C ? src[((long)b * C + c) * hw + r] : 0.f;
+    }
+    *(uint4*)(dst + p * Cp + g * VEC) = pack16<T>(f);
   }
 }
 
@@ -150,7 +160,7 @@ static int grid_for(long total) {
 
 int segk_nchw_to_nhwc_impl(const float* src, void* dst, int B, int C, int H, int W, int Cp, int dtype, hipStream_t st) {
   SEGK_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && Cp % 32 == 0, "nchw_to_nhwc: bad arguments");
-  const long total = (long)B * H * W * Cp;
+  const long total = (long)B * H * W * (Cp / (dtype == SEGK_DT_BF16 ? 8 : 4));
   if (dtype == SEGK_DT_BF16)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, src, (bf16_t*)dst, B, C, H, W, Cp);
   else
