@@ -299,6 +299,51 @@ def channel_sum(ptr, P, C, dtype, dev):
     return out
 
 
+_ZERO_GRADS = {}
+
+
+def _zero_grad_like(n, dev):
+    """Read-only all-zero fp32 vector, shared by every conv bias that sits ahead of a batch-statistics BatchNorm
+    (its gradient is identically zero): one allocation and one fill per (size, device) instead of one per layer
+    and step.  Nothing in the training path writes to a gradient other than scaling it, which keeps zeros zero."""
+    key = (n, str(dev))
+    t = _ZERO_GRADS.get(key)
+    if t is None:
+        t = torch.zeros(n, dtype=torch.float32, device=dev)
+        _ZERO_GRADS[key] = t
+    return t
+
+
+_NBT_DEFER = None
+
+
+class defer_batch_counters:
+    """Inside this context the BatchNorm `num_batches_tracked` increments of all DoubleConv blocks are collected and
+    applied by ONE fused foreach kernel on exit (18 one-element kernels per U-Net step otherwise)."""
+
+    def __enter__(self):
+        global _NBT_DEFER
+        self.prev, _NBT_DEFER = _NBT_DEFER, []
+        return self
+
+    def __exit__(self, *exc):
+        global _NBT_DEFER
+        pending, _NBT_DEFER = _NBT_DEFER, self.prev
+        if pending and exc[0] is None:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
+def _bump_batch_counters(*bns):
+    for bn in bns:
+        if bn.num_batches_tracked is None:
+            continue
+        if _NBT_DEFER is not None:
+            _NBT_DEFER.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+
+
 def _param_f32(p):
     t = p.detach()
     if t.dtype != torch.float32 or not t.is_contiguous():
@@ -353,8 +398,7 @@ class DoubleConvFn(torch.autograd.Function):
                                          _param_f32(be2), bn2.running_mean, bn2.running_var, mom2, bn2.eps, training,
                                          dev)
         if training:
-            bn1.num_batches_tracked.add_(1)
-            bn2.num_batches_tracked.add_(1)
+            _bump_batch_counters(bn1, bn2)
         y = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         with _span("bn_relu_apply", 0.0, 2.0 * P * Cout * _es(dtype)):
             _lib.call("segk_bn_relu_apply", z2.data_ptr(), y.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), P, Coutp,
@@ -399,15 +443,24 @@ class DoubleConvFn(torch.autograd.Function):
             w1d = mod.cache.get(("w1d", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 1))
             dxa_buf = torch.empty((B, H, W, CAp), dtype=dtype, device=dev)
             dxb_buf = torch.empty((B, H, W, CBp), dtype=dtype, device=dev) if CB else None
+            # with a concat operand (the ConvTranspose output of an Up block) the kernel's per-channel-sum epilogue
+            # also yields sum_pixels(dxb): exactly the bias gradient ConvT2x2Fn needs, without another pass over dxb
+            std = None
+            if CB:
+                tiles_d = _lib.query("segk_conv_tiles", B, H, W, Coutp, CAp + CBp, _DT[dtype])
+                std = _f32(_lib.query("segk_bn_stats_floats", tiles_d, CAp + CBp), dev)
             conv3x3(dz1, dz1.data_ptr(), Coutp, 0, 0, w1d, dxa_buf.data_ptr(), CAp, _p(dxb_buf), CBp, B, H, W, dtype,
-                    alg=(Cout, CA + CB))
+                    stats=std, alg=(Cout, CA + CB))
             dxa = act_view(dxa_buf, CA)
             dxb = act_view(dxb_buf, CB) if CB else None
+            if CB:
+                part = std[:tiles_d * (CAp + CBp) * 2].view(tiles_d, CAp + CBp, 2)
+                dxb._segk_channel_sum = part[:, CAp:CAp + CB, 0].sum(dim=0)
         slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev, alg=(Cout, CA + CB))
         dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev)
         # conv biases ahead of a batch-statistics BatchNorm have an identically zero gradient
-        db1 = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_bias[0] else None
-        db2 = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_bias[1] else None
+        db1 = _zero_grad_like(Cout, dev) if ctx.has_bias[0] else None
+        db2 = _zero_grad_like(Cout, dev) if ctx.has_bias[1] else None
         return None, dxa, dxb, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2
 
 
@@ -526,7 +579,11 @@ class ConvT2x2Fn(torch.autograd.Function):
             dx = act_view(dxb, Cin)
         slabs, S = wgrad(px, Cinp, pd, Coutp, 0, 0, B, H, W, 2, dtype, dev, alg=(Cin, Cout))
         dw = wgrad_to_param(slabs, S, w.shape, Cin, Cout, 0, 4, dev)
-        db = channel_sum(pd, B * 4 * H * W, Cout, dtype, dev) if ctx.has_bias else None
+        db = None
+        if ctx.has_bias:     # per-channel sum of dout: handed over by the producing conv when it already has it
+            db = getattr(dout, "_segk_channel_sum", None)
+            if db is None or db.shape != (Cout,):
+                db = channel_sum(pd, B * 4 * H * W, Cout, dtype, dev)
         return None, dx, dw, db
 
 

@@ -105,6 +105,10 @@ class unet(_FusedBase):
         return self
 
     def forward(self, x):
+        with ops.defer_batch_counters():     # one fused update of the 18 num_batches_tracked counters
+            return self._forward(x)
+
+    def _forward(self, x):
         x1 = self.down1(x)
         x2, s1 = self.down2(x1, return_skip=True)     # s1..s4 alias x1..x4 (the skip connections, unet.py:96-103)
         x3, s2 = self.down3(x2, return_skip=True)
