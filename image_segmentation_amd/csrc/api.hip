@@ -51,7 +51,8 @@ int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cin
 }
 
 int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype) {
-  const int bm = segk_conv_use_ws(Cin, Cout, dtype) ? 256 : segk_conv_bm(0, Cout);
+  const int pk = segk_conv_use_pipe(Cin, Cout, dtype);
+  const int bm = segk_conv_use_ws(Cin, Cout, dtype) ? 256 : pk ? 32768 / pk : segk_conv_bm(0, Cout);
   const int twl = segk_conv_twl(bm, W);
   return B * cdiv(W, 1 << twl) * cdiv(H, bm >> twl);
 }

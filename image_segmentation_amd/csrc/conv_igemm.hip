@@ -34,6 +34,15 @@
 int segk_conv_use_ws(int cin_p, int n_p, int dtype) {
   return dtype == SEGK_DT_BF16 && cin_p <= 64 && n_p % 64 == 0;   // bf16 performance mode only
 }
+// producer/consumer kernel (bf16 3x3, at least two 64-byte input chunks, not a weight-stationary layer): returns
+// its channel tile, 128 (256-pixel tiles) or 64 (512-pixel tiles, Cin >= 128: with K = 576 the unit boundary
+// dominates and the weight-stationary kernel wins), or 0
+int segk_conv_use_pipe(int cin_p, int n_p, int dtype) {
+  if (dtype != SEGK_DT_BF16 || segk_conv_use_ws(cin_p, n_p, dtype) || cin_p < 64) return 0;
+  if (n_p % 128 == 0) return 128;
+  if (n_p % 64 == 0 && cin_p >= 128) return 64;
+  return 0;
+}
 int segk_conv_bm(int geo, int unit) { return (unit % 128 == 0 || geo != 0) ? 256 : 128; }
 int segk_conv_twl(int bm, int W) { return bm == 128 ? 4 : (W > 16 ? 5 : 4); }   // 8x16 | 8x32 | 16x16 tiles
 
@@ -430,12 +439,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 //     step ahead.  Their waits (vmcnt, LDS-store queueing) no longer sit in any MFMA stream.
 // One s_barrier per step joins the two roles.  The weight ring keeps running across work units (the epilogue
 // tile overlays only [P0 | P1 | W2], dead at that point).  LDS: [W0 | W1 | P0 | P1 | W2], 80-byte pitch.
-template <int TWL, bool PRO>
+template <int TWL, bool PRO, int BN>
 __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) {
   using T = bf16_t;
   using E = ET<T>;
-  constexpr int BM = 256, BN = 128, NTHR = 512, NPT = 256;   // NPT: producer threads
-  constexpr int WM = 2, MF = 4, NF = 2;                       // consumer waves: 2 x 2, 128 px x 64 ch each
+  // workgroup tile 256 px x 128 ch (consumers 2 x 2) or, for 64-channel layers, 512 px x 64 ch (consumers 4 x 1):
+  // the same bytes per step and the same 128 x 64 consumer tile either way
+  static_assert(BN == 128 || BN == 64, "channel tile is 128 or 64");
+  constexpr int BM = 32768 / BN, NTHR = 512, NPT = 256;       // NPT: producer threads
+  constexpr int WN = BN / 64, WM = 4 / WN, MF = 4, NF = 2;    // consumer waves: WM x WN, 128 px x 64 ch each
   constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
   constexpr int ROWP = (PW * PIXB + 255) & ~255;
   constexpr int PB = PH * ROWP;                    // one patch chunk
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   }
 
   // ============================================= CONSUMERS =============================================
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave - wm * WN;
   const int lr = lane & 31, lh = lane >> 5;
   int laneA[MF], laneB[NF];
 #pragma unroll
@@ -1062,9 +1074,9 @@ int launch_ws(ConvArgs a, hipStream_t st) {
   return 0;
 }
 
-template <int TWL, bool PRO>
+template <int TWL, bool PRO, int BN>
 int launch_pipe(ConvArgs a, hipStream_t st) {
-  constexpr int BM = 256, BN = 128, NTHR = 512;
+  constexpr int BM = 32768 / BN, NTHR = 512;
   constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
   constexpr int ROWP = (PW * PIXB + 255) & ~255;
   constexpr size_t lds = 3 * (size_t)(3 * BN * PIXB) + 2 * (size_t)PH * ROWP + (NTHR / 2) * 16;   // + producers' trash slots
@@ -1077,7 +1089,7 @@ int launch_pipe(ConvArgs a, hipStream_t st) {
   int gw = num_cus() / 8;                                  // one 8-wave workgroup per CU
   if (gw > per_xcd) gw = per_xcd;
   a.persistent = 1;
-  auto kern = conv3x3_pipe_kernel<TWL, PRO>;
+  auto kern = conv3x3_pipe_kernel<TWL, PRO, BN>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1147,9 +1159,14 @@ int launch_geo(const ConvArgs& a, hipStream_t st) {
     }
   }
   if constexpr (GEO == 0 && sizeof(T) == 2) {
-    if (unit % 128 == 0 && a.CA + a.CB >= 64) {    // MFMA-bound bf16 layers: producer/consumer kernel
-      if (a.scale) return wide ? launch_pipe<5, true>(a, st) : launch_pipe<4, true>(a, st);
-      return wide ? launch_pipe<5, false>(a, st) : launch_pipe<4, false>(a, st);
+    const int pk = segk_conv_use_pipe(a.CA + a.CB, a.Ntot, SEGK_DT_BF16);   // MFMA-bound bf16 layers: producer/consumer kernel
+    if (pk == 128) {
+      if (a.scale) return wide ? launch_pipe<5, true, 128>(a, st) : launch_pipe<4, true, 128>(a, st);
+      return wide ? launch_pipe<5, false, 128>(a, st) : launch_pipe<4, false, 128>(a, st);
+    }
+    if (pk == 64) {
+      if (a.scale) return wide ? launch_pipe<5, true, 64>(a, st) : launch_pipe<4, true, 64>(a, st);
+      return wide ? launch_pipe<5, false, 64>(a, st) : launch_pipe<4, false, 64>(a, st);
     }
   }
   if constexpr (GEO == 1 && sizeof(T) == 2) {

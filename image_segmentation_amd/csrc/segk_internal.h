@@ -22,6 +22,7 @@ struct ConvArgs {
 };
 int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st);
 int segk_conv_use_ws(int cin_p, int n_p, int dtype);   // weight-stationary variant applies
+int segk_conv_use_pipe(int cin_p, int n_p, int dtype); // producer/consumer variant: its channel tile (128 | 64) or 0
 int segk_conv_bm(int geo, int unit);      // pixels per tile for a layer with N = unit output channels
 int segk_conv_twl(int bm, int W);         // log2 tile width
 
