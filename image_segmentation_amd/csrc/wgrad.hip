@@ -327,17 +327,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     return __builtin_shufflevector(f0, f1, 0, 1, 2, 3, 4, 5, 6, 7);
   };
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  // BatchNorm(scale, shift) + ReLU on the 8 pixels of one channel; vmask bit j = pixel j lies inside the image
+  // BatchNorm(scale, shift) + ReLU on the 8 pixels of one channel; vmask bit j = pixel j lies inside the image.
+  // Instruction count matters here (VALU issued beside the MFMAs): scalar fp32 fma (packed fp32 is slower next to
+  // MFMAs), one bf16 conversion per pair, the ReLU as a packed signed-16-bit max on the bf16 bit patterns
+  // (rounding to bf16 is monotonic and sign-preserving, so max(round(x), 0) == round(max(x, 0)) bit for bit),
+  // and the image-edge masking only on partial tiles.
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
   auto transform = [&](s16x8 v, unsigned vmask) {
     const uint4 raw = __builtin_bit_cast(uint4, v);
     float f[8];
     unpack16<T>(raw, f);
+    unsigned o[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      f[j] = fmaxf(fmaf(f[j], psc, psh), 0.f);
-      f[j] = ((vmask >> j) & 1) ? f[j] : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const float x0 = fmaf(f[2 * i], psc, psh), x1 = fmaf(f[2 * i + 1], psc, psh);
+      unsigned pk;
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x0), "v"(x1));
+      o[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2){0, 0}));
     }
-    return __builtin_bit_cast(s16x8, pack16<T>(f));
+    if (vmask != 0xffu) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        o[i] &= ((vmask >> (2 * i)) & 1 ? 0x0000ffffu : 0u) | ((vmask >> (2 * i + 1)) & 1 ? 0xffff0000u : 0u);
+    }
+    return __builtin_bit_cast(s16x8, make_uint4(o[0], o[1], o[2], o[3]));
   };
 
   int t = s, cur = 0;

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Collects the judged evidence on the MI355X box (run through gpurun from the repo root):
+#   bench line (default run), rocprofv3 kernel stats of the same command, FETCH_SIZE / WRITE_SIZE PMC passes.
+# Output under gpurun_out/final/ ; copy the summaries into profiles/ afterwards.
+set -e
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/final
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > /dev/null 2> $OUT/pmc_fetch.err
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > /dev/null 2> $OUT/pmc_write.err
+echo "write done"
+python - <<PY
+import csv, json, collections
+out = "$OUT"
+def fam(name):
+    if "conv3x3_pipe" in name or "conv_ws_kernel" in name: return "conv3x3"
+    if "conv_igemm_kernel" in name:
+        # GEO is the 2nd template argument: Li0E (mangled) / ", 0," demangled forms differ; ConvT/1x1 rows carry GEO 1
+        return "conv3x3" if ("Li0ELi" in name.split("conv_igemm_kernel")[1][:12] or "E, 0," in name) else "conv_other"
+    if "wgrad_dma_kernel" in name: return "wgrad3x3"
+    if "wgrad_kernel" in name: return "wgrad_other"
+    return None
+agg = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
+for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    for r in csv.DictReader(open(f"{out}/{d}/r_counter_collection.csv")):
+        f = fam(r["Kernel_Name"])
+        if f and r["Counter_Name"] == ctr:
+            agg[f][ctr].append(float(r["Counter_Value"]))
+res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 (separate passes)",
+       "unit": "KB per launch (rocprofv3 raw); FETCH_SIZE doubled for bytes on gfx950 (MI355X_MICROARCH.md HBM section)", "kernels": {}}
+for f, v in agg.items():
+    if not v["FETCH_SIZE"] or not v["WRITE_SIZE"]: continue
+    fe = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]); wr = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+    res["kernels"][f] = {"launches_sampled": len(v["FETCH_SIZE"]), "FETCH_SIZE_KB": round(fe, 1), "WRITE_SIZE_KB": round(wr, 1),
+                         "hbm_bytes_per_launch": int((2 * fe + wr) * 1024)}
+json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(res["kernels"], indent=1))
+PY
+cp $OUT/stats/r_kernel_stats.csv $OUT/kernel_stats.csv
+ls -la $OUT
