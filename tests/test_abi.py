@@ -52,7 +52,8 @@ def test_load_and_version(lib):
     assert so.segk_version() >= 100
     assert so.segk_last_error() is not None
     # pure size queries work without a GPU
-    assert lib.query("segk_conv_tiles", 2, 32, 32, 256, 64, 1) == 2 * 4 * 2    # 8x16 tiles: narrow output, long K
+    assert lib.query("segk_conv_tiles", 2, 32, 32, 256, 64, 1) == 2 * 2 * 1    # 16x32 tiles: bf16 64-ch output, long K
+    assert lib.query("segk_conv_tiles", 2, 32, 32, 256, 64, 0) == 2 * 4 * 2    # 8x16 tiles: the same layer in fp32
     assert lib.query("segk_conv_tiles", 2, 32, 32, 64, 64, 1) == 2 * 4 * 1     # 8x32 tiles: weight-stationary kernel
     assert lib.query("segk_conv_tiles", 2, 32, 32, 128, 128, 1) == 2 * 4 * 1   # 8x32 tiles for 128 channels
     assert lib.query("segk_bn_stats_floats", 4, 64) == 4 * 64 * 2 + 32 * 64 * 4
