@@ -68,6 +68,17 @@ int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const 
   return segk_conv_igemm_launch(a, 0, dtype, (hipStream_t)s);
 }
 
+int segk_conv_writes_act_q(int Cin, int Cout, int dtype) { return segk_conv_writes_act(Cin, Cout, dtype); }
+
+int segk_conv3x3_act(const void* srcA, const void* wpacked, const float* scale, const float* shift, void* out,
+                     void* act_out, float* stats, int B, int H, int W, int CA, int CO, int dtype, segk_stream_t s) {
+  ConvArgs a{};
+  a.srcA = srcA; a.w = wpacked; a.scale = scale; a.shift = shift; a.out = out; a.act_out = act_out; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.CA = CA; a.Ntot = CO; a.CO1 = CO;
+  fill_tiles(a);
+  return segk_conv_igemm_launch(a, 0, dtype, (hipStream_t)s);
+}
+
 int segk_conv1x1(const void* srcA, const void* wpacked, const float* bias, void* out, int B, int H, int W, int CA,
                  int CO, int dtype, segk_stream_t s) {
   ConvArgs a{};

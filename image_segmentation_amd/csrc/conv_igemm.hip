@@ -43,6 +43,9 @@ int segk_conv_use_pipe(int cin_p, int n_p, int dtype) {
   if (n_p % 64 == 0 && cin_p >= 128) return 64;
   return 0;
 }
+int segk_conv_writes_act(int cin_p, int n_p, int dtype) {
+  return segk_conv_use_ws(cin_p, n_p, dtype) || segk_conv_use_pipe(cin_p, n_p, dtype) != 0;
+}
 int segk_conv_bm(int geo, int unit) { return (unit % 128 == 0 || geo != 0) ? 256 : 128; }
 int segk_conv_twl(int bm, int W) { return bm == 128 ? 4 : (W > 16 ? 5 : 4); }   // 8x16 | 8x32 | 16x16 tiles
 
@@ -534,6 +537,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     const int trash = MAINB + ptid * 16;
     const int pc = ptid & 3;        // 16-byte slot inside the 64-byte chunk (NPT % 4 == 0: same for every piece)
     int plds[NPL], prel[NPL];
+    unsigned pint = 0;              // bit i: piece i is an interior (non-halo) pixel of the tile
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       const int q = ptid + i * NPT;
@@ -541,6 +545,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       const int py = pix / PW, px = pix - py * PW;
       plds[i] = (q < NP) ? POFF + py * ROWP + px * PIXB + pc * 16 : trash;
       prel[i] = (q < NP) ? ((py << 8) | px) : (0x7fff << 8);  // row 32767: outside every image, never valid
+      pint |= ((q < NP && py >= 1 && py <= TH && px >= 1 && px <= TW) ? 1u : 0u) << i;
     }
     unsigned wsrc[NWL];
     int wlds[NWL];
@@ -557,7 +562,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     unsigned pvalid = 0;
     int plin[NPL];
     float psc[E::VEC], psh[E::VEC];
-    auto patch_unit = [&](int b, int y0, int x0) {
+    int pl_aoff = -1;               // channel offset of the fetched chunk inside act_out (or -1)
+    bool pl_first = false;          // the fetched patch belongs to a unit of channel tile 0 (writes act_out)
+    auto patch_unit = [&](int b, int y0, int x0, int n0) {
+      pl_first = (n0 == 0);
       pvalid = 0;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
@@ -574,6 +582,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       if (kc < nchA) { base = (const T*)a.srcA; C = a.CA; coff = kc * E::CH; }
       else { base = (const T*)a.srcB; C = a.CB; coff = (kc - nchA) * E::CH; }
       base += coff + pc * E::VEC;
+      pl_aoff = (kc < nchA) ? coff + pc * E::VEC : -1;      // act_out mirrors srcA only
 #pragma unroll
       for (int i = 0; i < NPL; ++i) preg[i] = *(const u32x4*)(base + (size_t)(unsigned)(plin[i] * C));
       if (PRO) {
@@ -600,6 +609,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
         v = ok ? v : (u32x4){0u, 0u, 0u, 0u};
         const int off = (plds[i] < MAINB) ? plds[i] + pboff : trash;
         *(u32x4*)(smem + off) = v;
+        if (PRO) {   // side output: the transformed activation itself, interior pixels, once per pixel and chunk
+          if (a.act_out && pl_first && pl_aoff >= 0 && ok && ((pint >> i) & 1))
+            *(u32x4*)((T*)a.act_out + (size_t)(unsigned)(plin[i] * a.CA) + pl_aoff) = v;
+        }
       }
     };
 
@@ -630,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       int t0, t1, t2, t3;
       if (has_next) decode(un, t0, t1, t2, t3, nn0);
     }
-    patch_unit(ub, uy0, ux0);
+    patch_unit(ub, uy0, ux0, un0);
     patch_load(0);
     fetch_w(wreg[0]);
     fetch_w(wreg[1]);
@@ -661,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
         store_w(1, wreg[1]);
         fetch_w(wreg[0]);
         if (kc + 2 < nchunks) patch_load(kc + 2);
-        else if (kc + 2 == nchunks && has_next) { patch_unit(nb, ny0, nx0); patch_load(0); }
+        else if (kc + 2 == nchunks && has_next) { patch_unit(nb, ny0, nx0, nn0); patch_load(0); }
         __syncthreads();
       }
       __syncthreads();                                 // E1: the consumers have staged the output tile
@@ -845,6 +858,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvArgs a) {
   const int trash = MAINB + tid * 16;
   const int pc = tid & 3;
   int plds[NPL], prel[NPL];
+  unsigned pint = 0;                               // bit i: piece i is an interior (non-halo) pixel of the tile
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int q = tid + i * NTHR;
@@ -852,6 +866,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvArgs a) {
     const int py = pix / PW, px = pix - py * PW;
     plds[i] = (q < NP) ? py * ROWP + px * PIXB + pc * 16 : trash;
     prel[i] = (q < NP) ? ((py << 8) | px) : (0x7fff << 8);
+    pint |= ((q < NP && py >= 1 && py <= TH && px >= 1 && px <= TW) ? 1u : 0u) << i;
   }
   int laneA[MF], laneB;
 #pragma unroll
@@ -884,6 +899,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvArgs a) {
         psh[kc][j] = a.shift[c];
       }
   }
+  int plin[NPL];                                   // pixel index of each fetched piece (for the act_out side output)
   auto load_patch = [&](int b, int y0, int x0) {
     pvalid = 0;
 #pragma unroll
@@ -892,6 +908,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvArgs a) {
       const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
       const int cy = ok ? gy : y0, cx = ok ? gx : x0;
       const size_t lin = (size_t)(b * H + cy) * W + cx;
+      plin[i] = (int)lin;
       pvalid |= (ok ? 1u : 0u) << i;
 #pragma unroll
       for (int kc = 0; kc < MAXCH; ++kc) {
@@ -920,6 +937,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvArgs a) {
         v = ok ? v : (u32x4){0u, 0u, 0u, 0u};
         const int off = plds[i] + ((plds[i] < MAINB) ? kc * PB : 0);
         *(u32x4*)(smem + off) = v;
+        if (PRO) {   // side output: the transformed activation itself, interior pixels, once per pixel and chunk
+          if (a.act_out && nt == 0 && kc < nchunks && ok && ((pint >> i) & 1))
+            *(u32x4*)((T*)a.act_out + (size_t)(unsigned)plin[i] * a.CA + kc * E::CH + pc * E::VEC) = v;
+        }
       }
   };
 
@@ -1202,6 +1223,8 @@ int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st
   SEGK_REQUIRE(!(a.unshuf && (a.CB || geo != 1)), "conv_igemm: un-shuffle gather needs geo 1, single source");
   SEGK_REQUIRE(!(a.scale && (a.CB || geo != 0)), "conv_igemm: BN prologue needs the 3x3 geometry and one source");
   SEGK_REQUIRE((a.scale == nullptr) == (a.shift == nullptr), "conv_igemm: scale/shift must come together");
+  SEGK_REQUIRE(!a.act_out || (a.scale && geo == 0 && segk_conv_writes_act(a.CA + a.CB, a.Ntot, dtype)),
+               "conv_igemm: act_out needs the BN prologue and a layer served by the producer/consumer or weight-stationary kernel");
   SEGK_REQUIRE(a.Ntot > 0 && a.Ntot % 32 == 0, "conv_igemm: N=%d must be a multiple of 32", a.Ntot);
   SEGK_REQUIRE(a.CO1 > 0 && a.CO1 % 32 == 0 && a.CO2 >= 0 && a.CO2 % 32 == 0, "conv_igemm: bad output channels");
   if (a.shuffle) SEGK_REQUIRE(a.Ntot == 4 * a.CO1 && !a.out2 && geo == 1, "conv_igemm: pixel-shuffle needs N=4*Cout");

@@ -13,6 +13,8 @@ struct ConvArgs {
   void* out;            // [B,H,W,CO1]  (pixel-shuffle: [B,2H,2W,CO1])
   void* out2;           // optional second destination [B,H,W,CO2]
   float* stats;         // optional [tiles][Ntot][2] BN partial sums
+  void* act_out;        // optional [B,H,W,CA]: the prologue's BN+ReLU output of srcA, written once (producer/consumer and
+                        // weight-stationary kernels only: segk_conv_writes_act)
   int B, H, W;
   int CA, CB;
   int Ntot, CO1, CO2;
@@ -23,6 +25,7 @@ struct ConvArgs {
 int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st);
 int segk_conv_use_ws(int cin_p, int n_p, int dtype);   // weight-stationary variant applies
 int segk_conv_use_pipe(int cin_p, int n_p, int dtype); // producer/consumer variant: its channel tile (128 | 64) or 0
+int segk_conv_writes_act(int cin_p, int n_p, int dtype); // the layer's kernel can emit ConvArgs::act_out
 int segk_conv_bm(int geo, int unit);      // pixels per tile for a layer with N = unit output channels
 int segk_conv_twl(int bm, int W);         // log2 tile width
 

@@ -54,6 +54,13 @@ int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cin
  * scale/shift != NULL: the producer layer's BatchNorm+ReLU is applied to srcA on load (fused prologue).
  * stats != NULL: per-tile per-channel (sum, sumsq) partials [segk_conv_tiles()][CO1+CO2][2] for
  * training-mode BatchNorm (finish with segk_bn_finalize).  For the data gradient pass mode-1 weights. */
+/* Second conv of a DoubleConv block with its fused BN+ReLU prologue, additionally writing the prologue's result
+ * act_out[B,H,W,CA] = relu(srcA * scale + shift) (the hidden activation nn.Sequential would have materialised,
+ * unet.py:17-18): the weight-gradient pass then reads it directly instead of re-deriving it per fragment.
+ * Only for layers where segk_conv_writes_act_q(CA, CO, dtype) != 0; act_out may be NULL. */
+int segk_conv_writes_act_q(int Cin, int Cout, int dtype);
+int segk_conv3x3_act(const void* srcA, const void* wpacked, const float* scale, const float* shift, void* out,
+                     void* act_out, float* stats, int B, int H, int W, int CA, int CO, int dtype, segk_stream_t s);
 int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype);   /* padded CA+CB and CO1+CO2 of the call */
 /* floats to allocate for `stats`: the [tiles][Cp][2] partials plus the scratch segk_bn_finalize reduces through */
 int segk_bn_stats_floats(int tiles, int Cp);
