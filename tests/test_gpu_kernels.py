@@ -112,6 +112,69 @@ def test_conv3x3_prologue_and_dual(ops, dtype):
     assert (y - ref).abs().max().item() < tol(dtype, 1) * 2
 
 
+def test_conv3x3_bf16_persistent_units(ops):
+    """producer/consumer kernel with several work units per workgroup (the weight ring and the patch pipeline run
+    across unit boundaries) and the 512-pixel x 64-channel variant, against fp32 torch on the same bf16 inputs"""
+    dtype = torch.bfloat16
+    for B, Cin, Cout, H, W in [(4, 128, 256, 128, 128), (3, 128, 64, 96, 160)]:
+        x = fill((B, Cin, H, W), 11, -1, 1)
+        w = fill((Cout, Cin, 3, 3), 12, -1, 1) / np.sqrt(9 * Cin)
+        ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), padding=1)
+        y, st = _conv_direct(ops, x, w, dtype, stats=True)
+        assert (y - ref).abs().max().item() < tol(dtype, 1) * 1.5
+        s = st.sum(0)[:Cout]
+        assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2 * B * H * W * 0.05)
+        assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("C", [64, 128])
+def test_conv3x3_bf16_prologue_side_output(ops, C):
+    """segk_conv3x3_act (second conv of a block): conv(relu(z*scale+shift)) plus the hidden activation itself as a
+    side output, on an image with partial tiles; C = 64 runs the weight-stationary, 128 the producer/consumer kernel"""
+    from image_segmentation_amd import _lib
+    dtype = torch.bfloat16
+    B, H, W = 2, 40, 72
+    z = fill((B, C, H, W), 21, -2, 2); w = fill((C, C, 3, 3), 22, -1, 1) / np.sqrt(9 * C)
+    sc = fill((C,), 23, -1.5, 1.5); sh = fill((C,), 24, -0.5, 0.5)
+    assert _lib.query("segk_conv_writes_act_q", C, C, 1) == 1
+    a_ref = torch.relu(z.to(dtype).float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dtype).float()
+    ref = F.conv2d(a_ref, w.to(dtype).float(), padding=1)
+    za = ops.to_act(dev(z), dtype); pz, Cp = ops.act_info(za, dtype)
+    wp = ops.pack_conv(dev(w), C, 0, dtype, 0)
+    out = torch.empty((B, H, W, Cp), dtype=dtype, device="cuda")
+    act = torch.full((B, H, W, Cp), 7.0, dtype=dtype, device="cuda")
+    scd, shd = dev(sc), dev(sh)
+    _lib.call("segk_conv3x3_act", pz, wp.data_ptr(), scd.data_ptr(), shd.data_ptr(), out.data_ptr(), act.data_ptr(), 0,
+              B, H, W, Cp, Cp, 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (back(ops.act_view(out, C)) - ref).abs().max().item() < tol(dtype, 1) * 2
+    # every pixel and channel written exactly once with the bf16-rounded activation (fma vs mul+add: 1 bf16 ulp)
+    got = back(ops.act_view(act, C))
+    assert (got - a_ref).abs().max().item() <= 2 ** -7 * max(1.0, a_ref.abs().max().item())
+    assert ((got - a_ref).abs() > 0).float().mean().item() < 0.02
+
+
+def test_conv3x3_bf16_concat_and_split_gradient(ops):
+    """Up-block shapes on the producer/consumer kernel: two NHWC sources (skip | upsampled) forward, and the data
+    gradient written to two destinations (out | out2)"""
+    dtype = torch.bfloat16
+    B, H, W, CA, CB, Cout = 2, 24, 40, 64, 64, 128
+    xa = fill((B, CA, H, W), 31, -1, 1); xb = fill((B, CB, H, W), 32, -1, 1)
+    w = fill((Cout, CA + CB, 3, 3), 33, -1, 1) / np.sqrt(9 * (CA + CB))
+    ref = F.conv2d(torch.cat([xa, xb], 1).to(dtype).float(), w.to(dtype).float(), padding=1)
+    y = _conv_direct(ops, xa, w, dtype, xb=xb)
+    assert (y - ref).abs().max().item() < tol(dtype, 1) * 2
+    g = fill((B, Cout, H, W), 34, -1, 1)
+    refg = F.conv_transpose2d(g.to(dtype).float(), w.to(dtype).float(), padding=1)
+    ga = ops.to_act(dev(g), dtype); pg, Gp = ops.act_info(ga, dtype)
+    wd = ops.pack_conv(dev(w), CA, CB, dtype, 1)
+    o1 = torch.empty((B, H, W, CA), dtype=dtype, device="cuda"); o2 = torch.empty((B, H, W, CB), dtype=dtype, device="cuda")
+    ops.conv3x3(ga, pg, Gp, 0, 0, wd, o1.data_ptr(), CA, o2.data_ptr(), CB, B, H, W, dtype)
+    torch.cuda.synchronize()
+    got = torch.cat([back(ops.act_view(o1, CA)), back(ops.act_view(o2, CB))], 1)
+    assert (got - refg).abs().max().item() < tol(dtype, 1) * 2
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_dgrad_weights(ops, dtype):
     """mode-1 packing turns the same kernel into the data gradient"""
