@@ -165,6 +165,12 @@ def main():
         except Exception:
             pass
 
+    if B == 32 and S == 256 and args.loss == "ce":
+        cfg_name = "BASELINE config 2" if world == 1 else "BASELINE config 3"
+    elif B == 8 and S == 512 and args.loss == "dicece" and world == 1:
+        cfg_name = "BASELINE config 5"
+    else:
+        cfg_name = "custom configuration"
     img_s = world * B * args.steps / dt
     # DoubleConv-scope HBM roofline of SURVEY 8(d): kernels of the 9 DoubleConv blocks only
     dc_tags = ("conv3x3_igemm", "wgrad3x3", "wgrad_reduce", "bn_relu_bwd", "bn_relu_apply")
@@ -187,7 +193,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"unet(3,3) train step (fwd + {args.loss} + bwd + grad all-reduce + AdamW), "
-                               f"B={B}/GPU 3x{S}x{S}, BASELINE config {2 if world == 1 else 3}",
+                               f"B={B}/GPU 3x{S}x{S}, {cfg_name}",
                    "global_batch": B * world, "image": [3, S, S], "parallelism": f"dp{world}",
                    "final_loss": round(final_loss, 5)},
         "roofline": roofline, "cpu_baseline": cpu, "doubleconv_scope": scope, "kernels": kernels,
