@@ -88,7 +88,26 @@ def convt():
             print(f"convt {nm:5s} {cin}->{cout}@{hw}  {t:8.1f} us  {fl/t/1e6:7.1f} TF/s  {by/t/1e3:7.1f} GB/s(alg)")
 
 
+def bn():
+    """BatchNorm+ReLU backward (reduce + finalize + apply) and forward apply at the U-Net activation shapes."""
+    dt = torch.bfloat16
+    B = 32
+    for C, hw in [(64, 256), (128, 128), (256, 64), (512, 32), (1024, 16)]:
+        P = B * hw * hw
+        z = torch.randn((P, C), device="cuda").to(dt)
+        dy = torch.randn((P, C), device="cuda").to(dt)
+        dz = torch.empty_like(z)
+        sc = torch.rand(C, device="cuda") + 0.5; sh = torch.rand(C, device="cuda") - 0.5
+        mu = torch.zeros(C, device="cuda"); rs = torch.ones(C, device="cuda")
+        t = timeit(lambda: ops.bn_relu_bwd(dy.data_ptr(), z.data_ptr(), dz.data_ptr(), sc, sh, mu, rs, P, C, dt, "cuda"), 20)
+        by = 5.0 * P * C * 2
+        print(f"bn_bwd C={C:5d}@{hw:3d}  {t:8.1f} us  {by/t/1e3:7.1f} GB/s (5 passes)")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "bn":
+        bn()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "convt":
         convt()
         sys.exit(0)
