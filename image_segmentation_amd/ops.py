@@ -647,6 +647,58 @@ class Conv1x1Fn(torch.autograd.Function):
         return None, dx, dw, db
 
 
+class Conv3x3Fn(torch.autograd.Function):
+    """Plain nn.Conv2d(Cin, Cout, kernel_size=3, padding=1) with bias and no BatchNorm behind it -- the
+    reconstruction head of reference autoencoder/autoencoder.py:188-191 (the Sigmoid stays a stock torch op on the
+    small fp32 output).  Returns an act tensor."""
+
+    @staticmethod
+    def forward(ctx, mod, x, w, b):
+        dtype = mod.compute_dtype or _compute_dtype
+        _require_cuda(x, "Conv2d 3x3")
+        dev = x.device
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        Cinp, Coutp = pad32(Cin), pad32(Cout)
+        x_t, px, _ = _raw(x, dtype)
+        wp = mod.cache.get(("c3f", dtype), w, lambda: pack_conv(w, Cin, 0, dtype, 0))
+
+        def biasp():
+            t = torch.zeros((Coutp,), dtype=torch.float32, device=dev)
+            t[:Cout] = _param_f32(b)
+            return t
+        bp = None if b is None else mod.cache.get(("c3b", dtype), b, biasp)
+        out = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
+        P, e = B * H * W, _es(dtype)
+        with _span("conv3x3_igemm", 2.0 * P * 9 * Cin * Cout, P * (Cin + Cout) * e + 9.0 * Cin * Cout * e):
+            _lib.call("segk_conv3x3", px, 0, wp.data_ptr(), _p(bp), 0, 0, out.data_ptr(), 0, 0, B, H, W, Cinp, 0, Coutp, 0,
+                      _DT[dtype], _stream())
+        ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, Cin, Cout)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x_t, w)
+        return act_view(out, Cout)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x_t, w = ctx.saved_tensors
+        mod, dtype = ctx.mod, ctx.dtype
+        B, H, W, Cin, Cout = ctx.dims
+        dev = x_t.device
+        Cinp, Coutp = pad32(Cin), pad32(Cout)
+        d_t, pd, _ = _raw(dout, dtype)
+        px = act_info(x_t, dtype)[0]
+        dx = None
+        if ctx.needs_input_grad[1]:
+            wd = mod.cache.get(("c3d", dtype), w, lambda: pack_conv(w, Cin, 0, dtype, 1))
+            dxb = torch.empty((B, H, W, Cinp), dtype=dtype, device=dev)
+            conv3x3(d_t, pd, Coutp, 0, 0, wd, dxb.data_ptr(), Cinp, 0, 0, B, H, W, dtype, alg=(Cout, Cin))
+            dx = act_view(dxb, Cin)
+        slabs, S = wgrad(pd, Coutp, px, Cinp, 0, 0, B, H, W, 0, dtype, dev, alg=(Cout, Cin))
+        dw = wgrad_to_param(slabs, S, w.shape, Cout, Cin, 0, 9, dev)
+        db = channel_sum(pd, B * H * W, Cout, dtype, dev) if ctx.has_bias else None
+        return None, dx, dw, db
+
+
 class BilinearFn(torch.autograd.Function):
     """F.interpolate(x, size, mode='bilinear', align_corners=False) -- reference clip/clipunet.py:99-100."""
 

@@ -163,3 +163,40 @@ def test_losses_small(golden):
         close(l.grad, g[k + "_grad"], rtol=1e-4, atol=1e-8)
     with pytest.raises(ValueError):                       # reference rejects [N,H,W] for bare Dice
         losses_ref.soft_dice(lg0, Y)
+
+
+def _check_grad_summary(model, g, rtol=2e-4, atol=2e-6):
+    norms = dict(zip([str(n) for n in g["gnames"]], g["gnorms"]))
+    heads = dict(zip([str(n) for n in g["gnames"]], g["gheads"]))
+    for n, p in model.named_parameters():
+        gr = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert abs(gr.double().norm().item() - norms[n]) <= rtol * norms[n] + atol, n
+        h = gr.flatten()[:8].numpy()
+        close(h, heads[n][:h.size], rtol=2e-3, atol=2e-5)
+
+
+def test_autoencoder_family(golden):
+    """oracle/autoencoder_ref.py vs goldens from the imported reference autoencoder/autoencoder.py"""
+    from oracle import autoencoder_ref as ae
+    x = fill((2, 3, 32, 32), 1, 0, 1)
+    y = labels((2, 32, 32), 2, 3)
+    g = golden("autoencoder_seg_b2_32")
+    m = ae.SegmentationAutoencoder(3, base_channels=32, num_classes=3, freeze_encoder=False); fill_module(m, 3000); m.train()
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, y); loss.backward()
+    close(logits.detach(), g["logits"], atol=2e-5); assert abs(loss.item() - float(g["loss"])) < 1e-5
+    _check_grad_summary(m, g)
+    close(m.encoder.encoder.encoderPart1.bn1.running_mean, g["buf.encoder.encoder.encoderPart1.bn1.running_mean"])
+    close(m.decoder.decoderBlock3.convs[4].running_var, g["buf.decoder.decoderBlock3.convs.4.running_var"])
+    gf = golden("autoencoder_seg_frozen_b2_32")
+    mf = ae.SegmentationAutoencoder(3, base_channels=32, num_classes=3, freeze_encoder=True); fill_module(mf, 3000); mf.train()
+    lf = torch.nn.functional.cross_entropy(mf(x), y); lf.backward()
+    assert abs(lf.item() - float(gf["loss"])) < 1e-5
+    assert all(p.grad is None for p in mf.encoder.parameters())
+    _check_grad_summary(mf, gf)
+    gr = golden("autoencoder_rec_b2_32")
+    r = ae.ReconstructionAutoencoder(3, 3, base_channels=32); fill_module(r, 4000); r.train()
+    rec = r(x)
+    lr_ = torch.nn.functional.mse_loss(rec, x); lr_.backward()
+    close(rec.detach(), gr["rec"], atol=2e-6); assert abs(lr_.item() - float(gr["loss"])) < 1e-6
+    _check_grad_summary(r, gr)

@@ -227,4 +227,41 @@ def gen_trainloop():
 
 
 gen_trainloop()
+
+
+# ---- autoencoder family: reference autoencoder/autoencoder.py ------------------------------------
+def gen_autoencoder():
+    import io, contextlib
+    from autoencoder.autoencoder import SegmentationAutoencoder as RefSegAE, ReconstructionAutoencoder as RefRecAE
+    B, H = 2, 32
+    x = fill((B, 3, H, H), 1, 0, 1)
+    y = labels((B, H, H), 2, 3)
+    # segmentation autoencoder, trainable encoder, CE loss (training.py:47 style step)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = RefSegAE(3, base_channels=32, num_classes=3, freeze_encoder=False)
+    fill_module(m, 3000); m.train()
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    names, norms, heads = grad_summary(m)
+    save("autoencoder_seg_b2_32", logits=npy(logits), loss=np.array(loss.item()), gnames=names, gnorms=norms, gheads=heads,
+         **{k: v for k, v in buffers(m).items() if "encoderPart1.bn1" in k or "decoderBlock3.convs.4" in k})
+    # frozen encoder: only decoder / head parameters receive gradients
+    with contextlib.redirect_stdout(io.StringIO()):
+        mf = RefSegAE(3, base_channels=32, num_classes=3, freeze_encoder=True)
+    fill_module(mf, 3000); mf.train()
+    lf = torch.nn.functional.cross_entropy(mf(x), y)
+    lf.backward()
+    names, norms, heads = grad_summary(mf)
+    save("autoencoder_seg_frozen_b2_32", loss=np.array(lf.item()), gnames=names, gnorms=norms, gheads=heads)
+    # reconstruction autoencoder, MSE against the input
+    r = RefRecAE(3, 3, base_channels=32); fill_module(r, 4000); r.train()
+    rec = r(x)
+    lr_ = torch.nn.functional.mse_loss(rec, x)
+    lr_.backward()
+    names, norms, heads = grad_summary(r)
+    save("autoencoder_rec_b2_32", rec=npy(rec), loss=np.array(lr_.item()), gnames=names, gnorms=norms, gheads=heads)
+
+
+gen_autoencoder()
 print("done")
