@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--loss", choices=["ce", "dicece"], default="ce")
     ap.add_argument("--profile-steps", type=int, default=3, help="instrumented steps for the roofline block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to rehearse "
+                    "the multi-rank code path on a box with fewer GPUs than ranks")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -57,11 +60,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     seg.set_compute_dtype(dtype)
