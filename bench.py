@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--loss", choices=["ce", "dicece"], default="ce")
+    ap.add_argument("--model", choices=["unet", "clipunet"], default="unet",
+                    help="clipunet = BASELINE config 4 (use --batch 16 --size 224): frozen ViT-B/16 (local random-weight "
+                         "config) + HIP decoder, 4 classes; not the headline metric")
     ap.add_argument("--profile-steps", type=int, default=3, help="instrumented steps for the roofline block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to rehearse "
@@ -75,15 +78,20 @@ def main():
     seg.set_compute_dtype(dtype)
     B, S = args.batch, args.size
     torch.manual_seed(1234)                       # identical random-init weights on every rank
-    model = seg.unet(3, 3).to(dev).train()
-    opt = torch.optim.AdamW(model.parameters(), weight_decay=0.01, fused=True)
+    ncls = 3
+    if args.model == "clipunet":
+        ncls = 4
+        model = seg.ClipUNet(num_classes=4, encoder=seg.ClipViTEncoder.from_config()).to(dev).train()
+    else:
+        model = seg.unet(3, 3).to(dev).train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], weight_decay=0.01, fused=True)
     if args.loss == "ce":
         loss_fn = seg.CrossEntropyLoss()
     else:
         cw = torch.tensor([0.2046795970925636, 1.0271954434416883, 1.2293222812780409])
         loss_fn = seg.WeightedDiceCELoss(smooth_dice=1.0, class_weights=cw)
     X = fill((B, 3, S, S), 1 + 2 * rank, 0, 1).to(dev)           # images resident in HBM before timing
-    Y = labels((B, S, S), 2 + 2 * rank, 3).to(dev)
+    Y = labels((B, S, S), 2 + 2 * rank, ncls).to(dev)
     gs = GradSync(model) if world > 1 else None
 
     def step():
@@ -173,7 +181,9 @@ def main():
         except Exception:
             pass
 
-    if B == 32 and S == 256 and args.loss == "ce":
+    if args.model == "clipunet":
+        cfg_name = "BASELINE config 4" if (B == 16 and S == 224 and world == 1) else "custom configuration"
+    elif B == 32 and S == 256 and args.loss == "ce":
         cfg_name = "BASELINE config 2" if world == 1 else "BASELINE config 3"
     elif B == 8 and S == 512 and args.loss == "dicece" and world == 1:
         cfg_name = "BASELINE config 5"
@@ -192,7 +202,7 @@ def main():
                  "frac_of_6.29TBps_copy": round(gbps * 1e9 / HBM_COPY, 4)}
 
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.model == "unet":
         cpu = cpu_baseline(S)
 
     out = {
@@ -200,8 +210,10 @@ def main():
         "value": round(img_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"unet(3,3) train step (fwd + {args.loss} + bwd + grad all-reduce + AdamW), "
-                               f"B={B}/GPU 3x{S}x{S}, {cfg_name}",
+        "config": {"workload": (f"unet(3,3) train step (fwd + {args.loss} + bwd + grad all-reduce + AdamW), "
+                                f"B={B}/GPU 3x{S}x{S}, {cfg_name}") if args.model == "unet" else
+                               (f"ClipUNet(4 classes) train step: frozen ViT-B/16 forward (random-init local config) + decoder "
+                                f"fwd + {args.loss} + bwd + AdamW, B={B}/GPU 3x{S}x{S}, {cfg_name}"),
                    "global_batch": B * world, "image": [3, S, S], "parallelism": f"dp{world}",
                    "final_loss": round(final_loss, 5)},
         "roofline": roofline, "cpu_baseline": cpu, "doubleconv_scope": scope, "kernels": kernels,

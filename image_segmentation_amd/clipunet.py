@@ -7,9 +7,11 @@ conv_block.{0,1,3,4}}, output_layer, encoder.clip_vit.*).
   UNetDecoder(encoder_hidden_dim, decoder_channels)          reference clip/clipunet.py:108-144
   ClipUNet(num_classes, decoder_channels, freeze_encoder, model_name, skip_indices)   :147-188
 
-The frozen ViT-B/16 encoder is third-party code (transformers.CLIPVisionModel) in the reference and stays
-stock here; the decoder -- ConvTranspose up-sampling, 1x1 skip projections (MFMA GEMMs), bilinear skip resize,
-concat-free bias-free DoubleConv blocks and the 1x1 head -- runs on the HIP kernels.  `model_name` may be a hub
+The ViT-B/16 encoder is third-party code (transformers.CLIPVisionModel) in the reference; here the stock module
+is kept as the parameter container (same `encoder.clip_vit.*` keys) and, frozen as in the reference, its forward
+runs on the HIP kernels too (vit.py: MFMA GEMMs for the patch projection and every nn.Linear, csrc/vit.hip for
+LayerNorm, attention and the token layout).  The decoder -- ConvTranspose up-sampling, 1x1 skip projections (MFMA
+GEMMs), bilinear skip resize, concat-free bias-free DoubleConv blocks and the 1x1 head -- runs on the HIP kernels.  `model_name` may be a hub
 id (needs network/cache, like the reference) or a local directory; `ClipViTEncoder.from_config` builds the same
 architecture from a local CLIPVisionConfig with random weights (offline use, tests, benchmarks).
 """
@@ -26,6 +28,7 @@ class ClipViTEncoder(nn.Module):
         super().__init__()
         from transformers import CLIPVisionModel, CLIPVisionConfig
         self.skip_indices = sorted(skip_indices)
+        self.compute_dtype = None      # None -> ops.get_compute_dtype()
         if _config is not None:
             self.config = _config
             self.clip_vit = CLIPVisionModel(_config)
@@ -55,6 +58,16 @@ class ClipViTEncoder(nn.Module):
             print(f"Input image size ({x.shape[2]}x{x.shape[3]}) doesn't match "
                   f"CLIP expected size ({self.config.image_size}x{self.config.image_size}). "
                   f"Behavior may be unexpected. Consider resizing input.")
+        if not any(p.requires_grad for p in self.clip_vit.parameters()):
+            # frozen feature extractor (the reference default, clipunet.py:28-30): forward-only HIP path
+            from . import vit
+            plan = self.__dict__.get("_plan")
+            if plan is None:
+                plan = vit.ClipVisionPlan()
+                object.__setattr__(self, "_plan", plan)
+            dtype = self.compute_dtype or ops.get_compute_dtype()
+            return vit.forward_features(self.clip_vit, plan, x, self.skip_indices, dtype)
+        # fine-tuning the encoder (freeze_encoder=False): third-party autograd of the stock module on the GPU
         outputs = self.clip_vit(pixel_values=x, output_hidden_states=True)
         n = x.shape[0]
         bottleneck = self._grid(outputs.last_hidden_state, n)
@@ -131,7 +144,7 @@ class ClipUNet(_FusedBase):
 
     def set_compute_dtype(self, dtype):
         for m in self.modules():
-            if isinstance(m, _FusedBase):
+            if isinstance(m, (_FusedBase, ClipViTEncoder)):
                 m.compute_dtype = dtype
         return self
 

@@ -88,6 +88,18 @@ int segk_conv1x1(const void* srcA, const void* wpacked, const float* bias, void*
   return segk_conv_igemm_launch(a, 1, dtype, (hipStream_t)s);
 }
 
+int segk_linear(const void* rows, const void* wpacked, const float* bias, void* out, long M, int K, int N, int act,
+                int dtype, segk_stream_t s) {
+  // [M][K] x [K][N] (+ bias, optional quick_gelu): the 1x1-convolution GEMM over a 16-pixel-wide strip of M/16 rows
+  SEGK_REQUIRE(M > 0 && M % 16 == 0 && M / 16 < (1 << 24), "linear: M=%ld must be a positive multiple of 16", M);
+  SEGK_REQUIRE(act == 0 || act == 1, "linear: bad activation %d", act);
+  ConvArgs a{};
+  a.srcA = rows; a.w = wpacked; a.bias = bias; a.out = out;
+  a.B = 1; a.H = (int)(M / 16); a.W = 16; a.CA = K; a.Ntot = N; a.CO1 = N; a.act = act;
+  fill_tiles(a);
+  return segk_conv_igemm_launch(a, 1, dtype, (hipStream_t)s);
+}
+
 int segk_convt2x2_fwd(const void* in, const void* wpacked, const float* bias4, void* out, int B, int H, int W, int Cin,
                       int Cout, int dtype, segk_stream_t s) {
   // bias4: per-N bias of length 4*Cout (the layer bias repeated for the four taps) or NULL

@@ -308,6 +308,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           v[r] = acc[mf][nf][r] + bv;
+          if constexpr (GEO == 1) {   // CLIP MLP: quick_gelu(x) = x * sigmoid(1.702 x) fused behind fc1 (segk_linear)
+            if (a.act) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
+          }
           if (!FULL) {   // pixels past the image edge are never stored and must not enter the statistics
             const int m = mb + (r & 3) + 8 * (r >> 2);
             v[r] = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v[r] : 0.f;

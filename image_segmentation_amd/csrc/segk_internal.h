@@ -21,6 +21,7 @@ struct ConvArgs {
   int twl, tiles_x, tiles_y;
   int unshuf, shuffle;
   int persistent;       // set by the launcher
+  int act;              // 1x1 geometry only: 1 = quick_gelu on (acc + bias) (CLIP MLP fc1)
 };
 int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st);
 int segk_conv_use_ws(int cin_p, int n_p, int dtype);   // weight-stationary variant applies

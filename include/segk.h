@@ -128,6 +128,30 @@ int segk_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, int OH, int
 int segk_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,
                       segk_stream_t s);
 
+/* ---- CLIP vision transformer, frozen feature extractor (clip/clipunet.py:25-46,48-63 drive transformers'
+ * CLIPVisionModel -- third party; algorithm: modeling_clip.py CLIPVisionEmbeddings / CLIPEncoderLayer / CLIPAttention /
+ * CLIPMLP).  Token tensors are row matrices [Mp][C], Mp = B*T rounded up to 16 rows; the residual stream is fp32. */
+/* nn.Linear / patch-projection GEMM on MFMA: out[M][N] = rows[M][K] . W^T (+ bias) (act 1: quick_gelu, CLIPMLP).
+ * wpacked = segk_pack_conv_weight(W viewed as [N][K][1][1], taps 1, mode 0); K, N multiples of 32; M multiple of 16. */
+int segk_linear(const void* rows, const void* wpacked, const float* bias, void* out, long M, int K, int N, int act,
+                int dtype, segk_stream_t s);
+/* image NCHW fp32 [B,C,H,W] -> patch rows [B*(H/ps)*(W/ps)][Kp], k = c*ps*ps + i*ps + j (zero beyond C*ps*ps):
+ * the im2col of CLIPVisionEmbeddings.patch_embedding (Conv2d(C, D, ps, stride ps, bias=False)) */
+int segk_vit_patchify(const float* x, void* rows, int B, int C, int H, int W, int ps, int Kp, int dtype, segk_stream_t s);
+/* h[b][t] = LayerNorm_pre( (t == 0 ? class_embedding : proj[b][t-1]) + position_embedding[t] ); h fp32 [B*T][D] */
+int segk_vit_embed_ln(const void* proj, const float* cls, const float* pos, const float* gamma, const float* beta,
+                      float eps, float* h, int B, int T, int D, int Dp, int dtype, segk_stream_t s);
+/* residual add + LayerNorm: h[M][D] += delta[M][Dp] (delta may be NULL); out[M][Dp] = LN(h)*gamma+beta (out may be
+ * NULL: add only) -- CLIPEncoderLayer's residual connections fused with the next layer_norm1/2 */
+int segk_add_layernorm(float* h, const void* delta, const float* gamma, const float* beta, float eps, void* out, long M,
+                       int D, int Dp, int dtype, segk_stream_t s);
+/* CLIPAttention: qkv [B*T][ldq] = [q | k | v] (heads*head_dim each) -> ctx [B*T][ldo] = softmax(q k^T * scale) v per
+ * head; head_dim 32 or 64; the head's K and V must fit the 160 KiB LDS (T <= 320 fp32 / 640 bf16 at head_dim 64) */
+int segk_attention(const void* qkv, void* ctx, int B, int T, int heads, int head_dim, int ldq, int ldo, float scale,
+                   int dtype, segk_stream_t s);
+/* drop CLS, residual stream -> NHWC feature grid [B,G,G,Dp] in dtype (clipunet.py:48-51,54-63) */
+int segk_vit_tokens_to_grid(const float* h, void* out, int B, int T, int D, int Dp, int dtype, segk_stream_t s);
+
 /* ---- output head: Conv2d(C, ncls, 1) (unet.py:91,105; clipunet.py:181,187) ----------------------- */
 /* y NHWC [B,H,W,Cp] -> logits NCHW fp32 [B,ncls,H,W];  w fp32 [ncls][C], bias [ncls] */
 int segk_head_fwd(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp,

@@ -200,3 +200,27 @@ def test_autoencoder_family(golden):
     lr_ = torch.nn.functional.mse_loss(rec, x); lr_.backward()
     close(rec.detach(), gr["rec"], atol=2e-6); assert abs(lr_.item() - float(gr["loss"])) < 1e-6
     _check_grad_summary(r, gr)
+
+
+def small_vit():
+    transformers = pytest.importorskip("transformers")
+    cfg = transformers.CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=4,
+                                        num_attention_heads=2, image_size=80, patch_size=16)
+    m = transformers.CLIPVisionModel(cfg); fill_module(m, 8000); m.eval()
+    return m
+
+
+def test_clip_vit_restatement(golden):
+    """oracle/clip_vit_ref.py (plain-torch restatement of transformers' CLIP ViT) against the fixture captured from
+    the real CLIPVisionModel driven as reference clip/clipunet.py:41-63 drives it."""
+    from oracle import clip_vit_ref
+    g = golden("clip_vit_small")
+    m = small_vit()
+    x = fill((2, 3, 80, 80), 9, -1, 1)
+    hs = clip_vit_ref.hidden_states(m, x)
+    assert len(hs) == int(g["n_hidden"]) == 5
+    bott, skips = clip_vit_ref.encoder_features(m, x, [3, 1, 2])
+    close(bott.numpy(), g["bottleneck"], rtol=1e-4, atol=2e-5)
+    for i, sk in zip((1, 2, 3), skips):
+        close(sk.numpy(), g[f"skip{i}"], rtol=1e-4, atol=2e-5)
+    close(hs[-1][:, 0].numpy(), g["cls_last"], rtol=1e-4, atol=2e-5)

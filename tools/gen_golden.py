@@ -27,6 +27,13 @@ OUT = os.path.join(ROOT, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(8)
 META = {"torch": torch.__version__, "threads": torch.get_num_threads(), "dtype": "float32"}
+ONLY = os.environ.get("GOLDEN_ONLY")      # e.g. GOLDEN_ONLY=clip_vit regenerates one family; unset = all
+
+
+def want(family):
+    return ONLY is None or ONLY == family
+
+
 CW3 = [0.2046795970925636, 1.0271954434416883, 1.2293222812780409]
 
 
@@ -74,8 +81,9 @@ def gen_doubleconv(tag, din, dout, shape, base=1000):
         save(tag + "_eval", y=npy(m(fill(shape, 1, -1, 1))))
 
 
-gen_doubleconv("doubleconv_3_8", 3, 8, (2, 3, 16, 16))
-gen_doubleconv("doubleconv_32_64", 32, 64, (2, 32, 24, 40))
+if want("doubleconv"):
+    gen_doubleconv("doubleconv_3_8", 3, 8, (2, 3, 16, 16))
+    gen_doubleconv("doubleconv_32_64", 32, 64, (2, 32, 24, 40))
 
 
 # ---- Down / Up blocks ---------------------------------------------------------------------------
@@ -94,7 +102,7 @@ def gen_up():
     save("up_64_32", y=npy(y), dx1=npy(x1.grad), dx2=npy(x2.grad), **full_grads(m), **buffers(m))
 
 
-gen_down(); gen_up()
+if want("downup"): gen_down(); gen_up()
 
 
 # ---- B: unet(3,3) on 4x3x128x128 (BASELINE config 1; SURVEY 8c answer B) ------------------------
@@ -136,7 +144,7 @@ def gen_unet():
          grad_heads=h2)
 
 
-gen_unet()
+if want("unet"): gen_unet()
 
 
 # ---- C/D: CLIP decoder (SURVEY 8c answers C, D) -------------------------------------------------
@@ -170,10 +178,39 @@ def gen_clip():
          grad_heads=heads, argmax_sample=npy(lg.argmax(1)[:, ::4, ::4]).astype(np.uint8))
 
 
-gen_clip()
+if want("clip"): gen_clip()
 
 
 # ---- losses on small logits with ignore_index, incl. gradient wrt logits ------------------------
+def small_vit_config():
+    from transformers import CLIPVisionConfig
+    return CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=4, num_attention_heads=2,
+                            image_size=80, patch_size=16)
+
+
+def gen_clip_vit():
+    """The third-party encoder driven exactly as the reference's ClipViTEncoder.forward does (clipunet.py:41-63):
+    CLIPVisionModel(pixel_values, output_hidden_states=True); last_hidden_state and hidden_states[i] without CLS,
+    reshaped to [B,D,G,G].  Local random config (no hub access), portable-fill weights base 8000."""
+    from transformers import CLIPVisionModel
+    cfg = small_vit_config()
+    m = CLIPVisionModel(cfg); fill_module(m, 8000); m.eval()
+    x = fill((2, 3, 80, 80), 9, -1, 1)
+    with torch.no_grad():
+        out = m(pixel_values=x, output_hidden_states=True)
+    g = cfg.image_size // cfg.patch_size
+
+    def grid(hs):
+        return npy(hs[:, 1:, :].reshape(2, g, g, cfg.hidden_size).permute(0, 3, 1, 2).contiguous())
+    save("clip_vit_small", bottleneck=grid(out.last_hidden_state),
+         **{f"skip{i}": grid(out.hidden_states[i]) for i in (1, 2, 3)},
+         cls_last=npy(out.last_hidden_state[:, 0]), n_hidden=np.array(len(out.hidden_states)),
+         transformers=np.array(__import__("transformers").__version__))
+
+
+if want("clip_vit"): gen_clip_vit()
+
+
 def gen_losses():
     out = {}
     lg0 = fill((2, 4, 12, 20), 41, -3, 3)
@@ -196,7 +233,7 @@ def gen_losses():
     save("losses_small", **out)
 
 
-gen_losses()
+if want("losses"): gen_losses()
 
 
 # ---- train_loop protocol (training.py:18-64 driven by hand: torchvision/tqdm.notebook absent) ---
@@ -226,7 +263,7 @@ def gen_trainloop():
     save("trainloop_unet_32", **res)
 
 
-gen_trainloop()
+if want("trainloop"): gen_trainloop()
 
 
 # ---- autoencoder family: reference autoencoder/autoencoder.py ------------------------------------
@@ -263,5 +300,5 @@ def gen_autoencoder():
     save("autoencoder_rec_b2_32", rec=npy(rec), loss=np.array(lr_.item()), gnames=names, gnorms=norms, gheads=heads)
 
 
-gen_autoencoder()
+if want("autoencoder"): gen_autoencoder()
 print("done")
