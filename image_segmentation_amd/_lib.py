@@ -55,6 +55,10 @@ SIGNATURES = {
     "segk_loss_state_floats": (_i, []),
     "segk_loss_fwd": (_i, [_fp, _vp, _fp, _i, _i, _l, _i, _f, _f, _f, _fp, _fp, _vp]),
     "segk_loss_bwd": (_i, [_fp, _vp, _fp, _fp, _fp, _i, _i, _l, _i, _f, _f, _fp, _vp]),
+    "segk_prompt_mix_fwd": (_i, [_fp, _fp, _fp, _i, _l, _vp]),
+    "segk_prompt_mix_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _l, _vp]),
+    "segk_prob_loss_fwd": (_i, [_fp, _vp, _fp, _i, _i, _l, _i, _f, _f, _f, _i, _f, _fp, _fp, _vp]),
+    "segk_prob_loss_bwd": (_i, [_fp, _vp, _fp, _fp, _fp, _i, _i, _l, _i, _f, _f, _i, _f, _fp, _vp]),
     "segk_confusion": (_i, [_fp, _vp, _i, _i, _l, _vp, _vp]),
 }
 

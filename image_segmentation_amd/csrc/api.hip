@@ -23,9 +23,10 @@ int segk_head_fwd_impl(const void*, const float*, const float*, float*, int, int
 int segk_head_bwd_impl(const float*, const void*, const float*, void*, float*, float*, float*, int, int, int, int, int,
                        int, int, hipStream_t);
 int segk_loss_fwd_impl(const float*, const long long*, const float*, int, int, long, int, float, float, float, float*,
-                       float*, hipStream_t);
+                       float*, int, int, float, hipStream_t);
 int segk_loss_bwd_impl(const float*, const long long*, const float*, const float*, const float*, int, int, long, int,
-                       float, float, float*, hipStream_t);
+                       float, float, float*, int, int, float, hipStream_t);
+int segk_prompt_mix_impl(const float*, const float*, const float*, float*, int, long, hipStream_t);
 int segk_confusion_impl(const float*, const long long*, int, int, long, unsigned long long*, hipStream_t);
 
 static void fill_tiles(ConvArgs&) {}   // tile geometry is chosen per kernel configuration by the launcher
@@ -169,13 +170,34 @@ int segk_head_bwd(const float* dlogits, const void* y, const float* w, void* dy,
 int segk_loss_fwd(const float* logits, const int64_t* labels, const float* cw, int N, int C, long HW, int ignore_index,
                   float smooth, float dice_weight, float ce_weight, float* part, float* state, segk_stream_t s) {
   return segk_loss_fwd_impl(logits, (const long long*)labels, cw, N, C, HW, ignore_index, smooth, dice_weight, ce_weight,
-                            part, state, (hipStream_t)s);
+                            part, state, 0, 0, 0.f, (hipStream_t)s);
+}
+int segk_prob_loss_fwd(const float* probs, const int64_t* labels, const float* cw, int N, int C, long HW, int ignore_index,
+                       float smooth, float dice_weight, float nll_weight, int nll_log, float eps, float* part, float* state,
+                       segk_stream_t s) {
+  return segk_loss_fwd_impl(probs, (const long long*)labels, cw, N, C, HW, ignore_index, smooth, dice_weight, nll_weight,
+                            part, state, 1, nll_log, eps, (hipStream_t)s);
+}
+int segk_prob_loss_bwd(const float* probs, const int64_t* labels, const float* cw, const float* state, const float* gout,
+                       int N, int C, long HW, int ignore_index, float dice_weight, float nll_weight, int nll_log, float eps,
+                       float* dprobs, segk_stream_t s) {
+  return segk_loss_bwd_impl(probs, (const long long*)labels, cw, state, gout, N, C, HW, ignore_index, dice_weight,
+                            nll_weight, dprobs, 1, nll_log, eps, (hipStream_t)s);
+}
+int segk_prompt_mix_fwd(const float* clip_logits, const float* mask_logit, float* final_probs, int N, long HW,
+                        segk_stream_t s) {
+  return segk_prompt_mix_impl(clip_logits, mask_logit, nullptr, final_probs, N, HW, (hipStream_t)s);
+}
+int segk_prompt_mix_bwd(const float* clip_logits, const float* mask_logit, const float* dfinal, float* dmask_logit, int N,
+                        long HW, segk_stream_t s) {
+  SEGK_REQUIRE(dfinal, "prompt_mix_bwd: null gradient");
+  return segk_prompt_mix_impl(clip_logits, mask_logit, dfinal, dmask_logit, N, HW, (hipStream_t)s);
 }
 int segk_loss_bwd(const float* logits, const int64_t* labels, const float* cw, const float* state, const float* gout,
                   int N, int C, long HW, int ignore_index, float dice_weight, float ce_weight, float* dlogits,
                   segk_stream_t s) {
   return segk_loss_bwd_impl(logits, (const long long*)labels, cw, state, gout, N, C, HW, ignore_index, dice_weight,
-                            ce_weight, dlogits, (hipStream_t)s);
+                            ce_weight, dlogits, 0, 0, 0.f, (hipStream_t)s);
 }
 int segk_confusion(const float* logits, const int64_t* labels, int N, int C, long HW, uint64_t* M, segk_stream_t s) {
   return segk_confusion_impl(logits, (const long long*)labels, N, C, HW, (unsigned long long*)M, (hipStream_t)s);

@@ -177,10 +177,14 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// PROB: the input already holds class probabilities (prompt model, prompt_based/prompt.py:33-56): Dice on the values
+// themselves (weighted_loss.py:206-209 with apply_softmax=False) and NLLLoss on nll_nonlin(x) = log(x + eps)
+// (nll_log, prompt.ipynb's stable_log) or on x itself (weighted_loss.py:338-340)
+template <bool PROB>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ logits,
                                                        const long long* __restrict__ labels,
                                                        const float* __restrict__ cw, long P, long HW, int C,
-                                                       int ignore_index, float* __restrict__ part) {
+                                                       int ignore_index, float* __restrict__ part, int nll_log, float eps) {
   __shared__ float sh[4];
   float acc[LP];
 #pragma unroll
@@ -196,10 +200,11 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
     float se = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
-      l[k] = (k < C) ? expf(raw[k] - m) : 0.f;
+      if constexpr (PROB) l[k] = (k < C) ? raw[k] : 0.f;
+      else l[k] = (k < C) ? expf(raw[k] - m) : 0.f;
       se += l[k];
     }
-    const float inv = 1.f / se, lse = logf(se);
+    const float inv = PROB ? 1.f : 1.f / se, lse = PROB ? 0.f : logf(se);
     const long long y = labels[p];
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
       acc[2 + 2 * MAXC + k] += oh;
       if (y == k && k < C && y != ignore_index) {
         const float wy = cw ? cw[k] : 1.f;
-        acc[0] += wy * (lse - (raw[k] - m));   // -log softmax = log(sum exp) - (logit - max)
+        if constexpr (PROB) acc[0] += wy * (nll_log ? -logf(raw[k] + eps) : -raw[k]);
+        else acc[0] += wy * (lse - (raw[k] - m));   // -log softmax = log(sum exp) - (logit - max)
         acc[1] += wy;
       }
     }
@@ -272,12 +278,13 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
   (void)nvalid;
 }
 
+template <bool PROB>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits,
                                                        const long long* __restrict__ labels,
                                                        const float* __restrict__ cw, const float* __restrict__ state,
                                                        const float* __restrict__ gout, long P, long HW, int C,
                                                        int ignore_index, float dice_weight, float ce_weight,
-                                                       float* __restrict__ dlogits) {
+                                                       float* __restrict__ dlogits, int nll_log, float eps) {
   const float go = gout[0];
   const float ce_den = state[3];
   float G0[MAXC], G1[MAXC];   // dL_dice/dp_k = G0 + onehot*G1
@@ -298,14 +305,25 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
       l[k] = (k < C) ? logits[(b * C + k) * HW + r] : -INFINITY;
       m = fmaxf(m, l[k]);
     }
-    float se = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) { l[k] = (k < C) ? expf(l[k] - m) : 0.f; se += l[k]; }
-    const float inv = 1.f / se;
     const long long y = labels[p];
     const bool ce_valid = (y >= 0 && y < C && y != ignore_index);
     float wy = 0.f;
     if (ce_valid) wy = (cw ? cw[y] : 1.f) / ce_den;
+    if constexpr (PROB) {   // d/dx of  dice(x) + nll(log(x + eps) | x)
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k)
+        if (k < C) {
+          const bool hit = (y == k);
+          const float dd = G0[k] + (hit ? G1[k] : 0.f);
+          const float dn = hit ? (nll_log ? -wy / (l[k] + eps) : -wy) : 0.f;
+          dlogits[(b * C + k) * HW + r] = go * (dice_weight * dd + ce_weight * dn);
+        }
+      continue;
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) { l[k] = (k < C) ? expf(l[k] - m) : 0.f; se += l[k]; }
+    const float inv = 1.f / se;
     float dot = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
@@ -426,6 +444,62 @@ int segk_head_bwd_impl(const float* dlog, const void* y, const float* w, void* d
                                : head_bwd_t<float>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, st);
 }
 
+// ---- prompt model remix (prompt_based/prompt.py:33-56), 4 CLIP classes x 1 mask channel, fp32 NCHW ----
+//   p = softmax(clip_logits), m = sigmoid(mask_logit)
+//   final[0] = 1 - m;  final[1] = m*p0 + m*p3;  final[2] = m*p1;  final[3] = m*p2
+__global__ __launch_bounds__(256) void prompt_mix_fwd_kernel(const float* __restrict__ clip, const float* __restrict__ mask,
+                                                             float* __restrict__ out, long P, long HW) {
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    const long b = p / HW, r = p - b * HW;
+    float l[4], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { l[k] = clip[(b * 4 + k) * HW + r]; mx = fmaxf(mx, l[k]); }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { l[k] = expf(l[k] - mx); se += l[k]; }
+    const float inv = 1.f / se;
+    const float m = 1.f / (1.f + expf(-mask[p]));
+    float sel[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sel[k] = m * (l[k] * inv);
+    out[(b * 4 + 0) * HW + r] = 1.0f - m;
+    out[(b * 4 + 1) * HW + r] = sel[0] + sel[3];
+    out[(b * 4 + 2) * HW + r] = sel[1];
+    out[(b * 4 + 3) * HW + r] = sel[2];
+  }
+}
+// gradient w.r.t. the mask logit (the CLIP branch is frozen, prompt.py:30-31)
+__global__ __launch_bounds__(256) void prompt_mix_bwd_kernel(const float* __restrict__ clip, const float* __restrict__ mask,
+                                                             const float* __restrict__ dout, float* __restrict__ dmask,
+                                                             long P, long HW) {
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    const long b = p / HW, r = p - b * HW;
+    float l[4], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { l[k] = clip[(b * 4 + k) * HW + r]; mx = fmaxf(mx, l[k]); }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { l[k] = expf(l[k] - mx); se += l[k]; }
+    const float inv = 1.f / se;
+    const float m = 1.f / (1.f + expf(-mask[p]));
+    const float d0 = dout[(b * 4 + 0) * HW + r], d1 = dout[(b * 4 + 1) * HW + r];
+    const float d2 = dout[(b * 4 + 2) * HW + r], d3 = dout[(b * 4 + 3) * HW + r];
+    const float dm = -d0 + d1 * ((l[0] + l[3]) * inv) + d2 * (l[1] * inv) + d3 * (l[2] * inv);
+    dmask[p] = dm * m * (1.f - m);
+  }
+}
+
+int segk_prompt_mix_impl(const float* clip, const float* mask, const float* dout, float* out, int N, long HW, hipStream_t st) {
+  SEGK_REQUIRE(clip && mask && out && N > 0 && HW > 0, "prompt_mix: bad arguments");
+  const long P = (long)N * HW;
+  long g = (P + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (dout) hipLaunchKernelGGL(prompt_mix_bwd_kernel, dim3((int)g), dim3(256), 0, st, clip, mask, dout, out, P, HW);
+  else hipLaunchKernelGGL(prompt_mix_fwd_kernel, dim3((int)g), dim3(256), 0, st, clip, mask, out, P, HW);
+  SEGK_CHECK_LAUNCH("prompt_mix");
+  return 0;
+}
+
 int segk_loss_blocks(long P) {
   long g = (P + 255) / 256;
   return (int)(g > 512 ? 512 : g);
@@ -435,12 +509,13 @@ int segk_loss_state_floats(void) { return LS; }
 
 int segk_loss_fwd_impl(const float* logits, const long long* labels, const float* cw, int N, int C, long HW,
                        int ignore_index, float smooth, float dice_weight, float ce_weight, float* part, float* state,
-                       hipStream_t st) {
+                       int prob, int nll_log, float eps, hipStream_t st) {
   SEGK_REQUIRE(logits && labels && part && state && N > 0 && HW > 0, "loss_fwd: bad arguments");
   SEGK_REQUIRE(C >= 1 && C <= MAXC, "loss_fwd: 1..%d classes supported, got %d", MAXC, C);
   const long P = (long)N * HW;
   const int nb = segk_loss_blocks(P);
-  hipLaunchKernelGGL(loss_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part);
+  if (prob) hipLaunchKernelGGL(loss_fwd_kernel<true>, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part, nll_log, eps);
+  else hipLaunchKernelGGL(loss_fwd_kernel<false>, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part, 0, 0.f);
   SEGK_CHECK_LAUNCH("loss_fwd");
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, nb, C, cw, ignore_index, smooth, dice_weight, ce_weight, state);
   SEGK_CHECK_LAUNCH("loss_finalize");
@@ -449,12 +524,13 @@ int segk_loss_fwd_impl(const float* logits, const long long* labels, const float
 
 int segk_loss_bwd_impl(const float* logits, const long long* labels, const float* cw, const float* state,
                        const float* gout, int N, int C, long HW, int ignore_index, float dice_weight, float ce_weight,
-                       float* dlogits, hipStream_t st) {
+                       float* dlogits, int prob, int nll_log, float eps, hipStream_t st) {
   SEGK_REQUIRE(logits && labels && state && gout && dlogits && N > 0 && HW > 0 && C >= 1 && C <= MAXC, "loss_bwd: bad arguments");
   const long P = (long)N * HW;
   long g = (P + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)g), dim3(256), 0, st, logits, labels, cw, state, gout, P, HW, C, ignore_index, dice_weight, ce_weight, dlogits);
+  if (prob) hipLaunchKernelGGL(loss_bwd_kernel<true>, dim3((int)g), dim3(256), 0, st, logits, labels, cw, state, gout, P, HW, C, ignore_index, dice_weight, ce_weight, dlogits, nll_log, eps);
+  else hipLaunchKernelGGL(loss_bwd_kernel<false>, dim3((int)g), dim3(256), 0, st, logits, labels, cw, state, gout, P, HW, C, ignore_index, dice_weight, ce_weight, dlogits, 0, 0.f);
   SEGK_CHECK_LAUNCH("loss_bwd");
   return 0;
 }

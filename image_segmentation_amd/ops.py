@@ -816,6 +816,89 @@ class SegLossFn(torch.autograd.Function):
         return dl, None, None, None, None, None, None
 
 
+class ProbLossFn(torch.autograd.Function):
+    """dice_weight * softDice(p) + nll_weight * NLLLoss(log(p + eps) or p) on class PROBABILITIES (no softmax inside) --
+    reference utils/weighted_loss.py:170-343 as prompt_based/prompt.ipynb configures it (apply_softmax=False,
+    nll_nonlin = log(x + 1e-9))."""
+
+    @staticmethod
+    def forward(ctx, probs, target, class_weights, ignore_index, smooth, dice_weight, nll_weight, nll_log, eps):
+        _require_cuda(probs, "probability loss")
+        if probs.dim() != 4:
+            raise ValueError(f"expected probabilities [N,C,H,W], got {tuple(probs.shape)}")
+        N, C, H, W = probs.shape
+        if C > _lib.MAX_CLASSES:
+            raise RuntimeError(f"fused loss supports up to {_lib.MAX_CLASSES} classes, got {C}")
+        pr = probs.detach()
+        if pr.dtype != torch.float32 or not pr.is_contiguous():
+            pr = pr.float().contiguous()
+        tg = target.detach()
+        if tg.dtype != torch.int64 or not tg.is_contiguous():
+            tg = tg.long().contiguous()
+        if tg.numel() != N * H * W:
+            raise ValueError(f"target shape {tuple(target.shape)} does not match probabilities {tuple(probs.shape)}")
+        dev = probs.device
+        cw = None
+        if class_weights is not None:
+            cw = class_weights.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if cw.numel() != C:
+                raise ValueError("class_weights must have one entry per class")
+        ign = -1 if ignore_index is None else int(ignore_index)
+        part = _f32(_lib.query("segk_loss_part_floats", N * H * W), dev)
+        state = _f32(_lib.query("segk_loss_state_floats"), dev)
+        with _span("loss_fwd", 0.0, N * H * W * (4.0 * C + 8)):
+            _lib.call("segk_prob_loss_fwd", pr.data_ptr(), tg.data_ptr(), _p(cw), N, C, H * W, ign, float(smooth),
+                      float(dice_weight), float(nll_weight), int(nll_log), float(eps), part.data_ptr(), state.data_ptr(),
+                      _stream())
+        ctx.cfg = (N, C, H, W, ign, float(dice_weight), float(nll_weight), int(nll_log), float(eps))
+        ctx.save_for_backward(pr, tg, cw, state)
+        return state[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        pr, tg, cw, state = ctx.saved_tensors
+        N, C, H, W, ign, dw, nw, nll_log, eps = ctx.cfg
+        go = gout.detach().float().reshape(1).contiguous()
+        dp = torch.empty_like(pr)
+        with _span("loss_bwd", 0.0, N * H * W * (8.0 * C + 8)):
+            _lib.call("segk_prob_loss_bwd", pr.data_ptr(), tg.data_ptr(), _p(cw), state.data_ptr(), go.data_ptr(), N, C,
+                      H * W, ign, dw, nw, nll_log, eps, dp.data_ptr(), _stream())
+        return dp, None, None, None, None, None, None, None, None
+
+
+class PromptMixFn(torch.autograd.Function):
+    """final_probs of the prompt model (reference prompt_based/prompt.py:35-56): softmax of the frozen 4-class CLIP-UNet
+    logits remixed with the sigmoid of the mask U-Net's logit; gradient flows to the mask logit only (prompt.py:30-31)."""
+
+    @staticmethod
+    def forward(ctx, clip_logits, mask_logit):
+        _require_cuda(clip_logits, "prompt remix")
+        _require_cuda(mask_logit, "prompt remix")
+        N, C, H, W = clip_logits.shape
+        if C != 4 or tuple(mask_logit.shape) != (N, 1, H, W):
+            raise ValueError(f"prompt remix expects [N,4,H,W] CLIP logits and a [N,1,H,W] mask logit, got "
+                             f"{tuple(clip_logits.shape)} and {tuple(mask_logit.shape)}")
+        if clip_logits.requires_grad:
+            raise RuntimeError("prompt remix: the CLIP branch must be frozen (prompt.py:30-31); only the mask gets a gradient")
+        cl = clip_logits.detach().float().contiguous()
+        ml = mask_logit.detach().float().contiguous()
+        out = torch.empty_like(cl)
+        with _span("prompt_mix", 0.0, N * H * W * 36.0):
+            _lib.call("segk_prompt_mix_fwd", cl.data_ptr(), ml.data_ptr(), out.data_ptr(), N, H * W, _stream())
+        ctx.save_for_backward(cl, ml)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cl, ml = ctx.saved_tensors
+        N, _, H, W = cl.shape
+        d = dout.detach().float().contiguous()
+        dm = torch.empty_like(ml)
+        with _span("prompt_mix", 0.0, N * H * W * 40.0):
+            _lib.call("segk_prompt_mix_bwd", cl.data_ptr(), ml.data_ptr(), d.data_ptr(), dm.data_ptr(), N, H * W, _stream())
+        return None, dm
+
+
 def confusion_matrix(logits, labels, num_classes):
     """argmax over classes (first maximum, like torch.argmax) + confusion counts on device.
     logits [N,C,H,W] or [C,H,W]; labels [N,H,W] / [H,W].  Returns int64 [num_classes, num_classes] with

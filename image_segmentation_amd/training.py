@@ -130,7 +130,114 @@ def eval_loop(dataloader, model, loss_fn, device, target_size, agg):
     return avg_loss, mean_dice, mean_iou
 
 
-def start(
+def train_loop_prompt(dataloader, model, loss_fn, optimizer, accumulation_steps, device, scheduler=None, target_size=None,
+                      grad_sync=None):
+    """One epoch of the prompt model (training.py:153-199): batches are (image, heat-map, label) triples; otherwise
+    the accumulation / step / averaging protocol of train_loop."""
+    model.train()
+    total_loss = 0.0
+    processed_batches = 0
+
+    optimizer.zero_grad()
+
+    n = len(dataloader)
+    pbar = _bar(enumerate(dataloader), total=n, desc="Training")
+    for batch_idx, (X, p, y) in pbar:
+        if target_size is not None:
+            X, _ = process_batch_forward(X, target_size=target_size)
+            p, _ = process_batch_forward(p, target_size=target_size)
+            y, _ = process_batch_forward(y, target_size=target_size, interpolation=NEAREST)
+
+        X, p, y = X.to(device), p.to(device), y.to(device).long()
+        pred = model(X, p)
+        loss = loss_fn(pred, y.squeeze(1))
+
+        scaled_loss = loss / accumulation_steps
+        stepping = (batch_idx + 1) % accumulation_steps == 0 or (batch_idx + 1) == n
+        if grad_sync is not None and stepping:
+            grad_sync.arm()
+        scaled_loss.backward()
+
+        if stepping:
+            if grad_sync is not None:
+                grad_sync.sync()
+            optimizer.step()
+            if scheduler:
+                scheduler.step()
+            optimizer.zero_grad()
+
+            total_loss += loss.item()
+            processed_batches += 1
+            if hasattr(pbar, "set_postfix"):
+                pbar.set_postfix({'loss': loss.item(), 'lr': optimizer.param_groups[0]['lr']})
+
+    avg_loss = total_loss / processed_batches if processed_batches > 0 else 0
+    _say(f"Training Avg loss (per effective batch): {avg_loss:>8f}")
+    return avg_loss
+
+
+def eval_loop_prompt(dataloader, model, loss_fn, device, target_size, agg):
+    """training.py:242-296: eval_loop for (image, heat-map, label) batches; the heat-map takes the image's
+    resize + pad.  Returns (avg_loss, mean_dice, mean_iou)."""
+    model.eval()
+    num_images_processed = 0
+    total_loss = 0.0
+    num_classes = agg.get_num_classes()
+
+    with torch.no_grad():
+        for X, p, y in _bar(dataloader, desc="Eval"):
+            X, meta_list = process_batch_forward(X, target_size=target_size)
+            p, _ = process_batch_forward(p, target_size=target_size)
+            X, p = X.to(device), p.to(device)
+            preds = model(X, p)
+
+            preds = process_batch_reverse(preds, meta_list, interpolation='bilinear')
+
+            for pred, label in zip(preds, y):
+                pred = pred.to(device)
+                label = label.to(device).long()
+
+                loss = loss_fn(pred.unsqueeze(0), label.unsqueeze(0).squeeze(1))
+                total_loss += loss.item()
+                agg.accumulate(pred, label)
+
+                num_images_processed += 1
+
+    avg_loss = total_loss / num_images_processed
+
+    mean_dice, mean_iou, mean_acc = agg.compute_epoch_metrics()
+    per_class_iou = agg.get_last_per_class_iou()
+    ignore_index = agg.get_ignore_index()
+
+    _say(f"\n--- Evaluation Complete ---")
+    _say(f"  Images Processed: {num_images_processed}")
+    _say(f"  Average Loss (Original Size): {avg_loss:>8f}")
+    _say(f"  Ignored Class : {ignore_index}")
+    _say(f"  Macro Avg Acc score: {mean_acc:>8f}")
+    _say(f"  Macro Avg Dice Score: {mean_dice:>8f}")
+    _say(f"  Mean IoU (mIoU): {mean_iou:>8f}")
+    _say(f"  --- Per-Class IoU ---")
+    for c in range(num_classes):
+        _say(f"    Class {c}: {per_class_iou[c].item():>8f}")
+    _say("-" * 25)
+
+    return avg_loss, mean_dice, mean_iou
+
+
+def start(*args, **kwargs):
+    """training.py:453-618: optional resume, epoch loop, per-epoch metrics file, best-mIoU checkpoint
+    (+ weights-only "MO_<name>").  Checkpoint keys are the reference's."""
+    return _start(False, *args, **kwargs)
+
+
+def start_prompt(*args, **kwargs):
+    """training.py:299-450: `start` for the prompt model -- the prompt loops, a full (pickled) checkpoint load, the
+    metrics history stored inside the checkpoint and no weights-only "MO_" file."""
+    return _start(True, *args, **kwargs)
+
+
+def _start(
+        prompt: bool,
         model_save_dir: str,
         model_save_name: str,
         model,
@@ -151,8 +258,6 @@ def start(
         epochs: int = 100,
         grad_sync=None,
 ):
-    """training.py:453-618: optional resume, epoch loop, per-epoch metrics file, best-mIoU checkpoint
-    (+ weights-only "MO_<name>").  Checkpoint keys are the reference's."""
     start_epoch = 0
     best_dev_dice = -np.inf
     best_dev_miou = -np.inf
@@ -163,7 +268,7 @@ def start(
     path = f"{model_save_dir}/{model_save_name}"
     if load and os.path.isfile(path):
         _say(f"Loading checkpoint from: {path}")
-        checkpoint = torch.load(path, map_location=device, weights_only=True)
+        checkpoint = torch.load(path, map_location=device, weights_only=not prompt)   # training.py:351 vs :506
         model.load_state_dict(checkpoint["model_state_dict"])
         _say(" -> Model state loaded.")
         try:
@@ -198,9 +303,10 @@ def start(
     _say("\nStarting Training...")
     for t in range(start_epoch, epochs):
         _say(f"Epoch {t+1}\n-------------------------------")
-        train_loop(train_dataloader, model, train_loss_fn, optimizer, accumulation_steps, device, scheduler,
-                   target_size, grad_sync=grad_sync)
-        val_loss, val_dice, val_miou = eval_loop(val_dataloader, model, val_loss_fn, device, target_size, agg)
+        tl, el = (train_loop_prompt, eval_loop_prompt) if prompt else (train_loop, eval_loop)
+        tl(train_dataloader, model, train_loss_fn, optimizer, accumulation_steps, device, scheduler, target_size,
+           grad_sync=grad_sync)
+        val_loss, val_dice, val_miou = el(val_dataloader, model, val_loss_fn, device, target_size, agg)
 
         if save:
             torch.save({"epoch": t + 1, "history": agg}, f"{model_save_dir}/metrics/{model_save_name}")
@@ -220,9 +326,12 @@ def start(
                 }
                 if scheduler:
                     checkpoint["scheduler_state_dict"] = scheduler.state_dict()
+                if prompt:
+                    checkpoint["history"] = agg                      # training.py:424
                 torch.save(checkpoint, path)
-                torch.save({"epoch": t + 1, "model_state_dict": model.state_dict()},
-                           f"{model_save_dir}/MO_{model_save_name}")
+                if not prompt:
+                    torch.save({"epoch": t + 1, "model_state_dict": model.state_dict()},
+                               f"{model_save_dir}/MO_{model_save_name}")
         else:
             _say(f"Validation IoU score did not improve from {best_dev_miou:.6f}")
 

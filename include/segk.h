@@ -173,6 +173,24 @@ int segk_loss_bwd(const float* logits, const int64_t* labels, const float* class
                   const float* grad_out, int N, int C, long HW, int ignore_index, float dice_weight, float ce_weight,
                   float* dlogits, segk_stream_t s);
 
+/* ---- prompt model (prompt_based/prompt.py:33-56; utils/weighted_loss.py:170-343) ---------------------------
+ * remix of the frozen 4-class CLIP-UNet softmax with the sigmoid of the 1-channel mask U-Net, fp32 NCHW:
+ * final[0] = 1-m; final[1] = m*(p0+p3); final[2] = m*p1; final[3] = m*p2.  Backward: gradient of the mask logit only
+ * (the CLIP branch is frozen, prompt.py:30-31). */
+int segk_prompt_mix_fwd(const float* clip_logits, const float* mask_logit, float* final_probs, int N, long HW,
+                        segk_stream_t s);
+int segk_prompt_mix_bwd(const float* clip_logits, const float* mask_logit, const float* dfinal, float* dmask_logit, int N,
+                        long HW, segk_stream_t s);
+/* WeightedDiceNLLLoss on class probabilities (apply_softmax=False): soft Dice on the values themselves +
+ * NLLLoss(weight, ignore_index) of log(p + eps) (nll_log = 1; prompt.ipynb's stable_log) or of p itself (nll_log = 0).
+ * part/state sized like segk_loss_fwd's. */
+int segk_prob_loss_fwd(const float* probs, const int64_t* labels, const float* class_weights, int N, int C, long HW,
+                       int ignore_index, float smooth, float dice_weight, float nll_weight, int nll_log, float eps,
+                       float* part, float* state, segk_stream_t s);
+int segk_prob_loss_bwd(const float* probs, const int64_t* labels, const float* class_weights, const float* state,
+                       const float* grad_out, int N, int C, long HW, int ignore_index, float dice_weight,
+                       float nll_weight, int nll_log, float eps, float* dprobs, segk_stream_t s);
+
 /* ---- metric: argmax + confusion matrix (utils/MetricsHistory.py:65-75) ---------------------------
  * M[pred*8 + label] += count (uint64, caller zeroes); TP/FP/FN/TN follow on the host. */
 int segk_confusion(const float* logits, const int64_t* labels, int N, int C, long HW, uint64_t* M, segk_stream_t s);

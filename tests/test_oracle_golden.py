@@ -224,3 +224,59 @@ def test_clip_vit_restatement(golden):
     for i, sk in zip((1, 2, 3), skips):
         close(sk.numpy(), g[f"skip{i}"], rtol=1e-4, atol=2e-5)
     close(hs[-1][:, 0].numpy(), g["cls_last"], rtol=1e-4, atol=2e-5)
+
+
+CW4 = [0.2046795970925636, 1.0271954434416883, 1.2293222812780409, 0.5]
+PROMPT_VARIANTS = {
+    "prob_log": dict(apply_softmax=False, log_eps=1e-9, ignore_index=3, class_weights=CW4, smooth_dice=1),
+    "prob_log_plain": dict(apply_softmax=False, log_eps=1e-9),
+    "prob_identity": dict(apply_softmax=False, dice_weight=0.7, nll_weight=0.3),
+    "default_softmax": dict(class_weights=CW4),
+    "softmax_log": dict(log_eps=0.0, ignore_index=0),
+}
+
+
+def _nonlin(eps):
+    return None if eps is None else (lambda t: torch.log(t + eps))
+
+
+def test_prompt_model_and_losses(golden):
+    """oracle/prompt_ref.py against the fixture from the reference's PromptModel.forward and WeightedDiceNLLLoss."""
+    from oracle import prompt_ref
+    g = golden("prompt_small")
+    clip = unet_ref.unet(3, 4); mask = unet_ref.unet(4, 1)
+    fill_module(clip, 9000); fill_module(mask, 9500)
+    for p in clip.parameters():
+        p.requires_grad = False
+    clip.train(); mask.train()
+    x = fill((2, 3, 32, 48), 1, 0, 1); heat = fill((2, 1, 32, 48), 2, 0, 1)
+    y = labels((2, 32, 48), 3, 4)
+    final = prompt_ref.prompt_mix(clip(x), mask(torch.cat([x, heat], 1)))
+    close(final.detach().numpy(), g["final"], rtol=1e-4, atol=2e-6)
+    cw = torch.tensor(CW4)
+    loss = prompt_ref.dice_nll(final, y, ignore_index=3, class_weights=cw, smooth_dice=1, apply_softmax=False,
+                               nll_nonlin=_nonlin(1e-9))
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    loss.backward()
+    norms = {n: p.grad.double().norm().item() for n, p in mask.named_parameters()}
+    for n, ref in zip(g["gnames"], g["gnorms"]):
+        assert abs(norms[str(n)] - ref) <= 2e-4 * ref + 1e-9, n
+    pr = torch.softmax(fill((2, 4, 12, 20), 41, -3, 3), 1)
+    Y = labels((2, 12, 20), 42, 4)
+    for tag, kw in PROMPT_VARIANTS.items():
+        kw = dict(kw)
+        eps = kw.pop("log_eps", None)
+        if "class_weights" in kw:
+            kw["class_weights"] = torch.tensor(kw["class_weights"])
+        inp = pr.clone().requires_grad_(True)
+        l = prompt_ref.dice_nll(inp, Y, nll_nonlin=_nonlin(eps), **kw)
+        l.backward()
+        assert abs(l.item() - float(g[tag + ".loss"])) < 2e-6, tag
+        close(inp.grad.numpy(), g[tag + ".grad"], rtol=1e-4, atol=1e-8)
+    for tag, kw in {"dicep_prob": dict(apply_softmax=False, class_weights=cw, ignore_index=3, smooth=1),
+                    "dicep_softmax": dict()}.items():
+        inp = pr.clone().requires_grad_(True)
+        l = prompt_ref.dice_prompt(inp, Y, **kw)
+        l.backward()
+        assert abs(l.item() - float(g[tag + ".loss"])) < 2e-6, tag
+        close(inp.grad.numpy(), g[tag + ".grad"], rtol=1e-4, atol=1e-8)

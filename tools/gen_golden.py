@@ -236,6 +236,61 @@ def gen_losses():
 if want("losses"): gen_losses()
 
 
+CW4 = [0.2046795970925636, 1.0271954434416883, 1.2293222812780409, 0.5]
+
+
+def gen_prompt():
+    """The reference's own PromptModel.forward (prompt_based/prompt.py:33-56) and WeightedDiceNLLLoss, imported.  The
+    constructor cannot run offline (ClipUNet() fetches from the hub), so the instance is assembled by hand around the
+    reference's forward: `clip` = a frozen reference unet(3,4) standing in for the 4-class CLIP-UNet, `mask` = the
+    reference unet(4,1) exactly as prompt.py:16 builds it."""
+    from prompt_based.prompt import PromptModel as RefPrompt
+    from utils.weighted_loss import WeightedDiceNLLLoss as RefDiceNLL, WeightedMemoryEfficientDiceLossPrompt as RefDiceP
+    m = RefPrompt.__new__(RefPrompt)
+    torch.nn.Module.__init__(m)
+    m.clip = RefUnet(3, 4); m.mask = RefUnet(4, 1)
+    m.softmax = torch.nn.Softmax(dim=1); m.sigmoid = torch.nn.Sigmoid()
+    fill_module(m.clip, 9000); fill_module(m.mask, 9500)
+    for p in m.clip.parameters():
+        p.requires_grad = False
+    m.train()
+    x = fill((2, 3, 32, 48), 1, 0, 1); heat = fill((2, 1, 32, 48), 2, 0, 1)
+    y = labels((2, 32, 48), 3, 4)
+    cw = torch.tensor(CW4)
+    stable_log = lambda t: torch.log(t + 1e-9)       # prompt.ipynb cell 0
+    final = m(x, heat)
+    loss_fn = RefDiceNLL(ignore_index=3, smooth_dice=1, class_weights=cw, apply_softmax=False, nll_nonlin=stable_log)
+    loss = loss_fn(final, y)
+    loss.backward()
+    names, norms, heads = grad_summary(m.mask)
+    out = {"final": npy(final), "loss": np.array(loss.item()), "gnames": names, "gnorms": norms, "gheads": heads}
+    # the loss family on fixed probabilities / logits, values and input gradients
+    pr = torch.softmax(fill((2, 4, 12, 20), 41, -3, 3), 1)
+    Y = labels((2, 12, 20), 42, 4)
+    variants = {
+        "prob_log": dict(apply_softmax=False, nll_nonlin=stable_log, ignore_index=3, class_weights=cw, smooth_dice=1),
+        "prob_log_plain": dict(apply_softmax=False, nll_nonlin=stable_log),
+        "prob_identity": dict(apply_softmax=False, dice_weight=0.7, nll_weight=0.3),
+        "default_softmax": dict(class_weights=cw),
+        "softmax_log": dict(nll_nonlin=torch.log, ignore_index=0),
+    }
+    for tag, kw in variants.items():
+        inp = pr.clone().requires_grad_(True)
+        l = RefDiceNLL(**kw)(inp, Y if tag != "prob_log_plain" else Y.unsqueeze(1))
+        l.backward()
+        out[f"{tag}.loss"] = np.array(l.item()); out[f"{tag}.grad"] = npy(inp.grad)
+    for tag, kw in {"dicep_prob": dict(apply_softmax=False, class_weights=cw, ignore_index=3, smooth=1),
+                    "dicep_softmax": dict()}.items():
+        inp = pr.clone().requires_grad_(True)
+        l = RefDiceP(**kw)(inp, Y.unsqueeze(1))      # a [N,H,W] target fails the reference's own shape test (:213-217)
+        l.backward()
+        out[f"{tag}.loss"] = np.array(l.item()); out[f"{tag}.grad"] = npy(inp.grad)
+    save("prompt_small", **out)
+
+
+if want("prompt"): gen_prompt()
+
+
 # ---- train_loop protocol (training.py:18-64 driven by hand: torchvision/tqdm.notebook absent) ---
 def gen_trainloop():
     res = {}
