@@ -48,6 +48,8 @@ SIGNATURES = {
     "segk_add_layernorm": (_i, [_fp, _vp, _fp, _fp, _f, _vp, _l, _i, _i, _i, _vp]),
     "segk_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "segk_vit_tokens_to_grid": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "segk_resize_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_crop_resize": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_head_fwd": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_head_part_floats": (_i, [_l, _i]),
     "segk_head_bwd": (_i, [_fp, _vp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),

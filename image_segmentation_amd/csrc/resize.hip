@@ -123,3 +123,140 @@ extern "C" int segk_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW
   SEGK_CHECK_LAUNCH("bilinear_bwd");
   return 0;
 }
+
+// ---- eval-time pre/post-processing on device (reference utils/utils.py:13-115) -----------------------------
+// resize_pad: one image [C,H,W] -> its slot [C,T,T] of the network batch: aspect-preserving resize to (nh,nw) and
+// zero padding (utils.py:13-49).  The reference resizes with torchvision's TF.resize, whose tensor branch is
+// F.interpolate(mode, align_corners=False, antialias=True): ATen's separable anti-aliased triangle filter
+// (UpSampleKernel.cpp, _compute_indices_min_size_weights_aa): scale = in/out, support = max(scale,1),
+// center = scale*(o+0.5), taps [int(center-support+0.5), int(center+support+0.5)) clipped to the image,
+// w = 1-|(j-center+0.5)/max(scale,1)| normalised to sum 1; plain bilinear when up-scaling.  Labels use
+// mode "nearest": src = min(floor(o*scale), in-1).
+// crop_resize: slot [C,T,T] -> crop the (nh,nw) window -> [C,oh,ow] with F.interpolate bilinear
+// (align_corners=False, no anti-aliasing) or nearest (utils.py:51-75).
+namespace {
+
+struct AA {
+  int lo, n;
+  float center, inv, total;
+};
+__device__ __forceinline__ AA aa_taps(int o, float scale, int in_size) {
+  AA a;
+  const float support = scale >= 1.f ? scale : 1.f;
+  a.inv = scale >= 1.f ? 1.f / scale : 1.f;
+  a.center = scale * ((float)o + 0.5f);
+  int lo = (int)(a.center - support + 0.5f);
+  a.lo = lo < 0 ? 0 : lo;
+  int hi = (int)(a.center + support + 0.5f);
+  hi = hi > in_size ? in_size : hi;
+  a.n = hi - a.lo;
+  float t = 0.f;
+  for (int j = 0; j < a.n; ++j) {
+    const float x = fabsf(((float)(j + a.lo) - a.center + 0.5f) * a.inv);
+    t += x < 1.f ? 1.f - x : 0.f;
+  }
+  a.total = t;
+  return a;
+}
+__device__ __forceinline__ float aa_w(const AA& a, int j) {
+  const float x = fabsf(((float)(j + a.lo) - a.center + 0.5f) * a.inv);
+  const float w = x < 1.f ? 1.f - x : 0.f;
+  return a.total != 0.f ? w / a.total : w;
+}
+
+template <typename V>
+__global__ __launch_bounds__(256) void resize_pad_kernel(const V* __restrict__ img, V* __restrict__ out, int C, int H, int W,
+                                                         int nh, int nw, int T, int pt, int pl, int mode) {
+  const long total = (long)C * T * T;
+  const float sh = (float)H / (float)nh, sw = (float)W / (float)nw;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int tx = (int)(i % T);
+    const int ty = (int)((i / T) % T);
+    const int c = (int)(i / ((long)T * T));
+    const int oy = ty - pt, ox = tx - pl;
+    V v = (V)0;
+    if (oy >= 0 && oy < nh && ox >= 0 && ox < nw) {
+      const V* src = img + (size_t)c * H * W;
+      if (mode == 1) {
+        int sy = (int)floorf((float)oy * sh), sx = (int)floorf((float)ox * sw);
+        sy = sy > H - 1 ? H - 1 : sy;
+        sx = sx > W - 1 ? W - 1 : sx;
+        v = src[(size_t)sy * W + sx];
+      } else {
+        const AA ay = aa_taps(oy, sh, H), ax = aa_taps(ox, sw, W);
+        float acc = 0.f;
+        for (int jy = 0; jy < ay.n; ++jy) {
+          const float wy = aa_w(ay, jy);
+          float row = 0.f;
+          for (int jx = 0; jx < ax.n; ++jx) row = fmaf(aa_w(ax, jx), (float)src[(size_t)(ay.lo + jy) * W + ax.lo + jx], row);
+          acc = fmaf(wy, row, acc);
+        }
+        v = (V)acc;
+      }
+    }
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restrict__ slot, float* __restrict__ out, int C, int T,
+                                                          int pt, int pl, int nh, int nw, int oh, int ow, int mode) {
+  const long total = (long)C * oh * ow;
+  const float sh = (float)nh / (float)oh, sw = (float)nw / (float)ow;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ox = (int)(i % ow);
+    const int oy = (int)((i / ow) % oh);
+    const int c = (int)(i / ((long)oh * ow));
+    const float* src = slot + ((size_t)c * T + pt) * T + pl;       // window origin; row pitch T
+    float v;
+    if (mode == 1) {
+      int sy = (int)floorf((float)oy * sh), sx = (int)floorf((float)ox * sw);
+      sy = sy > nh - 1 ? nh - 1 : sy;
+      sx = sx > nw - 1 ? nw - 1 : sx;
+      v = src[(size_t)sy * T + sx];
+    } else {
+      int y0, y1, x0, x1;
+      float ly, lx;
+      src_index(oy, sh, nh, y0, y1, ly);
+      src_index(ox, sw, nw, x0, x1, lx);
+      const float a = src[(size_t)y0 * T + x0], b = src[(size_t)y0 * T + x1];
+      const float d = src[(size_t)y1 * T + x0], e = src[(size_t)y1 * T + x1];
+      // ATen: (1-ly)*((1-lx)*a + lx*b) + ly*((1-lx)*d + lx*e)
+      v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * d + lx * e);
+    }
+    out[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int segk_resize_pad(const void* img, void* out, int C, int H, int W, int nh, int nw, int T, int pad_top,
+                               int pad_left, int mode, int elem, segk_stream_t s) {
+  SEGK_REQUIRE(img && out && C > 0 && H > 0 && W > 0 && nh > 0 && nw > 0 && T > 0, "resize_pad: bad shape");
+  SEGK_REQUIRE(pad_top >= 0 && pad_left >= 0 && pad_top + nh <= T && pad_left + nw <= T, "resize_pad: window outside the target");
+  SEGK_REQUIRE((mode == 0 || mode == 1) && (elem == 0 || elem == 1), "resize_pad: bad mode/element type");
+  SEGK_REQUIRE(!(elem == 1 && mode == 0), "resize_pad: integer images resize with mode nearest only");
+  long g = ((long)C * T * T + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipStream_t st = (hipStream_t)s;
+  if (elem == 1)
+    hipLaunchKernelGGL(resize_pad_kernel<long long>, dim3((int)g), dim3(256), 0, st, (const long long*)img, (long long*)out, C, H, W,
+                       nh, nw, T, pad_top, pad_left, mode);
+  else
+    hipLaunchKernelGGL(resize_pad_kernel<float>, dim3((int)g), dim3(256), 0, st, (const float*)img, (float*)out, C, H, W, nh, nw, T,
+                       pad_top, pad_left, mode);
+  SEGK_CHECK_LAUNCH("resize_pad");
+  return 0;
+}
+
+extern "C" int segk_crop_resize(const float* slot, float* out, int C, int T, int pad_top, int pad_left, int nh, int nw, int oh,
+                                int ow, int mode, segk_stream_t s) {
+  SEGK_REQUIRE(slot && out && C > 0 && T > 0 && nh > 0 && nw > 0 && oh > 0 && ow > 0, "crop_resize: bad shape");
+  SEGK_REQUIRE(pad_top >= 0 && pad_left >= 0 && pad_top + nh <= T && pad_left + nw <= T, "crop_resize: window outside the slot");
+  SEGK_REQUIRE(mode == 0 || mode == 1, "crop_resize: bad mode");
+  long g = ((long)C * oh * ow + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(crop_resize_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, slot, out, C, T, pad_top, pad_left, nh, nw, oh,
+                     ow, mode);
+  SEGK_CHECK_LAUNCH("crop_resize");
+  return 0;
+}

@@ -28,10 +28,21 @@ class MetricsHistory:
         self.last_per_class_dice = None
         self.last_per_class_acc = None
         self.mask = torch.ones(num_classes, dtype=torch.bool)
+        self._dev_M = None              # device-resident confusion sums of accumulate_deferred (not pickled)
+        self._dev_pixels = 0
         if self.ignore_index is not None and 0 <= self.ignore_index < self.num_classes:
             self.mask[self.ignore_index] = False
 
+    def __getstate__(self):                 # checkpoints ("history": agg) carry the host totals only
+        self.flush()
+        d = dict(self.__dict__)
+        d["_dev_M"], d["_dev_pixels"] = None, 0
+        return d
+
     def reset(self):
+        if self._dev_M is not None:
+            self._dev_M.zero_()
+        self._dev_pixels = 0
         self.total_tp.zero_()
         self.total_fp.zero_()
         self.total_fn.zero_()
@@ -62,7 +73,38 @@ class MetricsHistory:
         self.total_fn += fn
         self.total_tn += tn
 
+    def accumulate_deferred(self, pred: torch.Tensor, label: torch.Tensor):
+        """`accumulate` without a host round trip per image (the eval loops' device path): counts are added to a
+        confusion matrix that stays on the GPU; `flush()` (called by compute_epoch_metrics) moves the sums over once.
+        The label range check of `accumulate` is made there too: a label outside [0, C) leaves the matrix short of
+        the pixel count."""
+        if not pred.is_cuda:
+            return self.accumulate(pred, label)
+        p = pred.squeeze(0) if pred.dim() == 4 else pred
+        lab = label.squeeze(0) if label.dim() == 3 else label
+        dev = p.device
+        if self._dev_M is None or self._dev_M.device != dev:
+            self.flush()
+            self._dev_M = torch.zeros((ops._lib.MAX_CLASSES, ops._lib.MAX_CLASSES), dtype=torch.int64, device=dev)
+        ops.confusion_matrix(p, lab.to(dev), self.num_classes, out=self._dev_M)
+        self._dev_pixels += lab.numel()
+
+    def flush(self):
+        if self._dev_M is None or self._dev_pixels == 0:
+            return
+        M = self._dev_M[:self.num_classes, :self.num_classes].cpu()
+        pixels, self._dev_pixels = self._dev_pixels, 0
+        self._dev_M.zero_()
+        if int(M.sum()) != pixels:
+            raise RuntimeError("Class values must be smaller than num_classes.")
+        tp, fp, fn, tn = self.counts_from_confusion(M, pixels)
+        self.total_tp += tp
+        self.total_fp += fp
+        self.total_fn += fn
+        self.total_tn += tn
+
     def compute_epoch_metrics(self, epsilon: float = 1e-6):
+        self.flush()
         tp, fp, fn, tn = self.total_tp, self.total_fp, self.total_fn, self.total_tn
         per_class_iou = tp / (tp + fp + fn)
         per_class_dice = (2 * tp) / (2 * tp + fp + fn)

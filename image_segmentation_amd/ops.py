@@ -899,7 +899,7 @@ class PromptMixFn(torch.autograd.Function):
         return None, dm
 
 
-def confusion_matrix(logits, labels, num_classes):
+def confusion_matrix(logits, labels, num_classes, out=None):
     """argmax over classes (first maximum, like torch.argmax) + confusion counts on device.
     logits [N,C,H,W] or [C,H,W]; labels [N,H,W] / [H,W].  Returns int64 [num_classes, num_classes] with
     M[pred, label] (reference utils/MetricsHistory.py:65-75 derives TP/FP/FN/TN from exactly these)."""
@@ -917,6 +917,7 @@ def confusion_matrix(logits, labels, num_classes):
         tg = tg.long().contiguous()
     if tg.numel() != N * H * W:
         raise ValueError("label shape does not match logits")
-    M = torch.zeros((_lib.MAX_CLASSES, _lib.MAX_CLASSES), dtype=torch.int64, device=logits.device)
+    # `out`: a persistent [MAX_CLASSES, MAX_CLASSES] int64 device matrix the counts are ADDED to (no allocation, no sync)
+    M = out if out is not None else torch.zeros((_lib.MAX_CLASSES, _lib.MAX_CLASSES), dtype=torch.int64, device=logits.device)
     _lib.call("segk_confusion", lg.data_ptr(), tg.data_ptr(), N, C, H * W, M.data_ptr(), _stream())
     return M[:C, :C]

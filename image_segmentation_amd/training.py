@@ -32,6 +32,12 @@ def _bar(it, **kw):
     return _tqdm(it, **kw)
 
 
+def _accumulate(agg, pred, label):
+    """MetricsHistory.accumulate, through the sync-free device path when the aggregator offers one."""
+    fn = getattr(agg, "accumulate_deferred", None)
+    (fn or agg.accumulate)(pred, label)
+
+
 def _say(*a):
     if VERBOSE:
         print(*a)
@@ -51,8 +57,8 @@ def train_loop(dataloader, model, loss_fn, optimizer, accumulation_steps, device
     pbar = _bar(enumerate(dataloader), total=n, desc="Training")
     for batch_idx, (X, y) in pbar:
         if target_size is not None:
-            X, _ = process_batch_forward(X, target_size=target_size)
-            y, _ = process_batch_forward(y, target_size=target_size, interpolation=NEAREST)
+            X, _ = process_batch_forward(X, target_size=target_size, device=device)
+            y, _ = process_batch_forward(y, target_size=target_size, interpolation=NEAREST, device=device)
 
         X, y = X.to(device), y.to(device).long()
         pred = model(X)
@@ -88,12 +94,13 @@ def eval_loop(dataloader, model, loss_fn, device, target_size, agg):
     model.eval()
     num_images_processed = 0
     total_loss = 0.0
+    total_dev = None
     num_classes = agg.get_num_classes()
     agg.reset()
 
     with torch.no_grad():
         for X, y in _bar(dataloader, desc="Eval"):
-            X, meta_list = process_batch_forward(X, target_size=target_size)
+            X, meta_list = process_batch_forward(X, target_size=target_size, device=device)
             X = X.to(device)
             preds = model(X)
 
@@ -104,11 +111,17 @@ def eval_loop(dataloader, model, loss_fn, device, target_size, agg):
                 label = label.to(device).long()
 
                 loss = loss_fn(pred.unsqueeze(0), label.unsqueeze(0).squeeze(1))
-                total_loss += loss.item()
-                agg.accumulate(pred, label)
+                if loss.is_cuda:        # device path: per-image losses and confusion counts stay on the GPU until the end
+                    total_dev = loss.detach().double() if total_dev is None else total_dev + loss.detach().double()
+                    _accumulate(agg, pred, label)
+                else:
+                    total_loss += loss.item()
+                    agg.accumulate(pred, label)
 
                 num_images_processed += 1
 
+    if total_dev is not None:
+        total_loss += total_dev.item()  # float64 sum of the float32 losses, as the reference's `+= loss.item()` builds
     avg_loss = total_loss / num_images_processed
 
     mean_dice, mean_iou, mean_acc = agg.compute_epoch_metrics()
@@ -144,9 +157,9 @@ def train_loop_prompt(dataloader, model, loss_fn, optimizer, accumulation_steps,
     pbar = _bar(enumerate(dataloader), total=n, desc="Training")
     for batch_idx, (X, p, y) in pbar:
         if target_size is not None:
-            X, _ = process_batch_forward(X, target_size=target_size)
-            p, _ = process_batch_forward(p, target_size=target_size)
-            y, _ = process_batch_forward(y, target_size=target_size, interpolation=NEAREST)
+            X, _ = process_batch_forward(X, target_size=target_size, device=device)
+            p, _ = process_batch_forward(p, target_size=target_size, device=device)
+            y, _ = process_batch_forward(y, target_size=target_size, interpolation=NEAREST, device=device)
 
         X, p, y = X.to(device), p.to(device), y.to(device).long()
         pred = model(X, p)
@@ -182,12 +195,13 @@ def eval_loop_prompt(dataloader, model, loss_fn, device, target_size, agg):
     model.eval()
     num_images_processed = 0
     total_loss = 0.0
+    total_dev = None
     num_classes = agg.get_num_classes()
 
     with torch.no_grad():
         for X, p, y in _bar(dataloader, desc="Eval"):
-            X, meta_list = process_batch_forward(X, target_size=target_size)
-            p, _ = process_batch_forward(p, target_size=target_size)
+            X, meta_list = process_batch_forward(X, target_size=target_size, device=device)
+            p, _ = process_batch_forward(p, target_size=target_size, device=device)
             X, p = X.to(device), p.to(device)
             preds = model(X, p)
 
@@ -198,11 +212,17 @@ def eval_loop_prompt(dataloader, model, loss_fn, device, target_size, agg):
                 label = label.to(device).long()
 
                 loss = loss_fn(pred.unsqueeze(0), label.unsqueeze(0).squeeze(1))
-                total_loss += loss.item()
-                agg.accumulate(pred, label)
+                if loss.is_cuda:        # device path: per-image losses and confusion counts stay on the GPU until the end
+                    total_dev = loss.detach().double() if total_dev is None else total_dev + loss.detach().double()
+                    _accumulate(agg, pred, label)
+                else:
+                    total_loss += loss.item()
+                    agg.accumulate(pred, label)
 
                 num_images_processed += 1
 
+    if total_dev is not None:
+        total_loss += total_dev.item()  # float64 sum of the float32 losses, as the reference's `+= loss.item()` builds
     avg_loss = total_loss / num_images_processed
 
     mean_dice, mean_iou, mean_acc = agg.compute_epoch_metrics()

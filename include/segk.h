@@ -152,6 +152,17 @@ int segk_attention(const void* qkv, void* ctx, int B, int T, int heads, int head
 /* drop CLS, residual stream -> NHWC feature grid [B,G,G,Dp] in dtype (clipunet.py:48-51,54-63) */
 int segk_vit_tokens_to_grid(const float* h, void* out, int B, int T, int D, int Dp, int dtype, segk_stream_t s);
 
+/* ---- eval-time pre/post-processing on device (utils/utils.py:13-115; training.py:87-99) ---------------------------
+ * one image [C,H,W] -> its slot [C,T,T] of the network batch: resize to (nh,nw) + zero padding (utils.py:13-49).
+ * mode 0: anti-aliased bilinear = F.interpolate(bilinear, align_corners=False, antialias=True), what torchvision's
+ * tensor TF.resize computes; mode 1: nearest.  elem 0: float32, 1: int64 (labels; mode 1 only). */
+int segk_resize_pad(const void* img, void* out, int C, int H, int W, int nh, int nw, int T, int pad_top, int pad_left,
+                    int mode, int elem, segk_stream_t s);
+/* slot [C,T,T] fp32 -> crop the (nh,nw) window at (pad_top,pad_left) -> [C,oh,ow]: F.interpolate bilinear
+ * (align_corners=False; mode 0) or nearest (mode 1) (utils.py:51-75) */
+int segk_crop_resize(const float* slot, float* out, int C, int T, int pad_top, int pad_left, int nh, int nw, int oh,
+                     int ow, int mode, segk_stream_t s);
+
 /* ---- output head: Conv2d(C, ncls, 1) (unet.py:91,105; clipunet.py:181,187) ----------------------- */
 /* y NHWC [B,H,W,Cp] -> logits NCHW fp32 [B,ncls,H,W];  w fp32 [ncls][C], bias [ncls] */
 int segk_head_fwd(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp,

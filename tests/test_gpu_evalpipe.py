@@ -1,0 +1,129 @@
+"""GPU (-m gpu): eval-time pre/post-processing on device (reference utils/utils.py:13-115, training.py:87-99):
+segk_resize_pad / segk_crop_resize and the sync-free loss / confusion accumulation of the eval loops, against the CPU
+oracle (oracle/resize_ref.py = the ATen calls torchvision's tensor resize makes; torchvision itself is absent, so
+parity with it is unpinned)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.fill import fill, labels, fill_module
+from oracle import resize_ref, unet_ref, losses_ref
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(3, 37, 53), (3, 500, 375), (3, 20, 30), (4, 64, 64), (3, 33, 65), (1, 90, 41), (3, 64, 17)]
+
+
+@pytest.fixture(scope="module")
+def seg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import image_segmentation_amd as s
+    return s
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("T", [32, 64])
+def test_forward_bilinear_antialiased(seg, T):
+    from image_segmentation_amd.utils import process_batch_forward
+    imgs = [fill(s, 10 + i, 0, 1) for i, s in enumerate(SHAPES) if s[0] in (3, 4)]
+    ref, rmeta = resize_ref.process_batch_forward(imgs, T)
+    out, meta = process_batch_forward(imgs, target_size=T, device="cuda")
+    assert out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == tuple(ref.shape)
+    assert meta == rmeta
+    assert np.abs(cpu(out) - ref.numpy()).max() < 2e-6
+    # the same images already resident on the device
+    out2, _ = process_batch_forward([im.cuda() for im in imgs], target_size=T)
+    assert torch.equal(out2, out)
+
+
+def test_forward_nearest_labels_exact(seg):
+    from image_segmentation_amd.utils import process_batch_forward, NEAREST
+    for dt in (torch.int64, torch.uint8, torch.float32):
+        labs = [labels((1,) + s[1:], 20 + i, 4).to(dt) for i, s in enumerate(SHAPES)]
+        ref, _ = resize_ref.process_batch_forward(labs, 48, nearest=True)
+        out, _ = process_batch_forward(labs, target_size=48, interpolation=NEAREST, device="cuda")
+        assert out.dtype == (torch.float32 if dt == torch.float32 else torch.int64)
+        assert np.array_equal(cpu(out).astype(np.int64), ref.numpy().astype(np.int64))
+
+
+@pytest.mark.parametrize("interp", ["bilinear", "nearest"])
+def test_reverse(seg, interp):
+    from image_segmentation_amd.utils import process_batch_forward, process_batch_reverse
+    T = 64
+    imgs = [fill(s, 10 + i, 0, 1) for i, s in enumerate(SHAPES) if s[0] == 3]
+    _, meta = process_batch_forward(imgs, target_size=T, device="cuda")
+    logits = fill((len(imgs), 4, T, T), 7, -3, 3)
+    ref = [resize_ref.reverse_resize_and_padding(l, m, interp) for l, m in zip(logits, meta)]
+    out = process_batch_reverse(logits.cuda(), meta, interpolation=interp)
+    for o, r, im in zip(out, ref, imgs):
+        assert o.is_cuda and tuple(o.shape) == (4,) + tuple(im.shape[1:])
+        # bilinear: the source coordinate scale*(o+0.5)-0.5 reaches ~64 (ulp 7.6e-6) on the 500-row image, and the
+        # interpolation weight inherits that rounding: 5e-5 on logits in [-3, 3]; nearest is exact
+        assert np.abs(cpu(o) - r.numpy()).max() < (5e-5 if interp == "bilinear" else 0.0) + 1e-12
+
+
+def test_resize_rejects_bad_windows(seg):
+    from image_segmentation_amd import _lib
+    t = torch.zeros(4096, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(RuntimeError, match="outside"):
+        _lib.call("segk_resize_pad", t.data_ptr(), t.data_ptr(), 1, 8, 8, 20, 20, 16, 0, 0, 0, 0, s)
+    with pytest.raises(RuntimeError, match="nearest only"):
+        _lib.call("segk_resize_pad", t.data_ptr(), t.data_ptr(), 1, 8, 8, 8, 8, 16, 0, 0, 0, 1, s)
+    with pytest.raises(RuntimeError, match="outside"):
+        _lib.call("segk_crop_resize", t.data_ptr(), t.data_ptr(), 1, 16, 10, 0, 8, 8, 4, 4, 0, s)
+
+
+def test_deferred_metrics_match_eager(seg):
+    from image_segmentation_amd.metrics import MetricsHistory
+    a, b = MetricsHistory(4, ignore_index=3), MetricsHistory(4, ignore_index=3)
+    for i, (h, w) in enumerate([(24, 32), (17, 9), (64, 64)]):
+        lg = fill((4, h, w), 50 + i, -2, 2).cuda(); lab = labels((h, w), 60 + i, 4).cuda()
+        a.accumulate(lg, lab); b.accumulate_deferred(lg, lab)
+    ra, rb = a.compute_epoch_metrics(), b.compute_epoch_metrics()
+    assert ra == rb
+    for x, y in ((a.total_tp, b.total_tp), (a.total_fp, b.total_fp), (a.total_fn, b.total_fn), (a.total_tn, b.total_tn)):
+        assert torch.equal(x, y)
+    import pickle
+    c = pickle.loads(pickle.dumps(b))                 # "history": agg inside checkpoints
+    assert torch.equal(c.total_tp, b.total_tp) and c._dev_M is None
+    bad = MetricsHistory(3)
+    bad.accumulate_deferred(fill((3, 8, 8), 1, -1, 1).cuda(), torch.full((8, 8), 3, dtype=torch.int64).cuda())
+    with pytest.raises(RuntimeError, match="smaller than num_classes"):
+        bad.compute_epoch_metrics()
+
+
+def test_eval_loop_device_path_vs_oracle(seg):
+    """eval_loop (training.py:67-121) end to end on ragged images: device resize + pad -> HIP U-Net (eval mode) ->
+    device crop + resize -> per-image loss and confusion counts, against the same protocol on the CPU oracle."""
+    from image_segmentation_amd import training
+    from image_segmentation_amd.metrics import MetricsHistory
+    seg.set_compute_dtype(torch.float32)
+    training.VERBOSE = False
+    m = seg.unet(3, 3); fill_module(m, 1000); m.cuda()
+    r = unet_ref.unet(3, 3); fill_module(r, 1000); r.eval()
+    sizes = [(40, 56), (64, 48), (33, 61), (64, 64)]
+    batches = [([fill((3,) + s, 70 + i, 0, 1) for i, s in enumerate(sizes[:2])], [labels((1,) + s, 80 + i, 3) for i, s in enumerate(sizes[:2])]),
+               ([fill((3,) + s, 72 + i, 0, 1) for i, s in enumerate(sizes[2:])], [labels((1,) + s, 82 + i, 3) for i, s in enumerate(sizes[2:])])]
+    agg = MetricsHistory(3)
+    loss, dice, miou = training.eval_loop(batches, m, seg.CrossEntropyLoss(), torch.device("cuda"), 64, agg)
+    ragg = MetricsHistory(3)
+    tot, n = 0.0, 0
+    with torch.no_grad():
+        for X, y in batches:
+            Xb, meta = resize_ref.process_batch_forward(X, 64)
+            preds = r(Xb)
+            for pr, mt, lab in zip(preds, meta, y):
+                pr = resize_ref.reverse_resize_and_padding(pr, mt)
+                tot += losses_ref.cross_entropy(pr.unsqueeze(0), lab.long()).item(); n += 1
+                ragg.accumulate(pr.cuda(), lab.cuda())
+    rd, ri, _ = ragg.compute_epoch_metrics()
+    assert abs(loss - tot / n) < 2e-5
+    # argmax ties aside the confusion counts are equal; allow a handful of flipped pixels out of ~13k
+    assert abs(miou - ri) < 2e-3 and abs(dice - rd) < 2e-3
+    training.VERBOSE = True
+    seg.set_compute_dtype(torch.bfloat16)
