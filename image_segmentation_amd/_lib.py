@@ -41,7 +41,7 @@ SIGNATURES = {
     "segk_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "segk_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "segk_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_bilinear_bwd": (_i, [_vp, _vp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_linear": (_i, [_vp, _vp, _fp, _vp, _l, _i, _i, _i, _i, _vp]),
     "segk_vit_patchify": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_vit_embed_ln": (_i, [_vp, _fp, _fp, _fp, _fp, _f, _fp, _i, _i, _i, _i, _i, _vp]),

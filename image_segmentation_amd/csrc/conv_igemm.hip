@@ -1193,6 +1193,19 @@ int launch_geo(const ConvArgs& a, hipStream_t st) {
     }
   }
   if constexpr (GEO == 1 && sizeof(T) == 2) {
+    // long-K GEMMs (ViT projections, ConvTranspose up-sampling and its data gradient): producer/consumer kernel
+    const int mode = a.shuffle ? 1 : (a.unshuf ? 2 : 0);
+    const int nchA = a.CA / 32, nchunks = a.unshuf ? 4 * nchA : nchA;
+    const long M = (long)a.B * a.H * a.W;
+    if (!a.srcB && !a.out2 && !a.stats && segk_gemm_pipe_ok(M, nchunks, nchA, a.Ntot, a.CO1, mode)) {
+      GemmArgs g{};
+      g.A = a.srcA; g.w = (const char*)a.w; g.bias = a.bias; g.out = a.out;
+      g.M = M; g.N = a.Ntot; g.nchunks = nchunks; g.nchA = nchA; g.lda = a.CA; g.H = a.H; g.W = a.W; g.Cout = a.CO1;
+      g.act = a.act;
+      return segk_gemm_pipe_launch(g, mode, st);
+    }
+  }
+  if constexpr (GEO == 1 && sizeof(T) == 2) {
     // 1x1 / ConvTranspose GEMMs have a short K (Cin) and are bound by their output epilogue: 128-pixel tiles on
     // 4-wave workgroups, two per CU, so one workgroup's epilogue overlaps the other's loads and MFMAs
     if (unit % 128 == 0) return launch_cfg<T, GEO, 4, 2, 2, 2, 2, 2>(a, st);

@@ -1,0 +1,322 @@
+// Producer/consumer bf16 GEMM on CDNA4 matrix cores (gfx950) for the 1x1 geometry with a long K:
+//   plain      out[M][N] = A[M][K] . W (+ bias, optional quick_gelu)      -- the CLIP ViT nn.Linear / patch projection
+//                                                                            GEMMs (segk_linear) and Conv2d 1x1
+//                                                                            (clip/clipunet.py:84,122)
+//   shuffle    ConvTranspose2d(k=2,s=2) forward (unet/unet.py:59, clip/clipunet.py:83): N = 4*Cout, the tile is
+//              stored pixel-shuffled into [B,2H,2W,Cout]
+//   unshuffle  its data gradient: K = 4*Cout gathered from the 2x2 output pixels of every input pixel
+// against the packed weights [K/32][N][32] of segk_pack_conv_weight / segk_pack_convt_weight.
+//
+// The generic streaming kernel (conv_igemm.hip) joins all waves at a barrier every 32 K-elements (8 MFMAs per wave);
+// with K = 768..3072 that leaves the matrix pipe idle most of the time (212 TFLOP/s on the ViT GEMMs, 386 on the
+// ConvTranspose GEMMs).  Here a 512-thread workgroup owns a 256 x 128 output tile; 4 CONSUMER waves (one per SIMD,
+// 128 x 64 each: 8 accumulator fragments) issue only ds_read_b128 + MFMA 32x32x16 -- 32 MFMAs between barriers -- and
+// 4 PRODUCER waves move the next 64-element K-stage global -> VGPR -> LDS one stage ahead (two LDS stage slots,
+// 80-byte row pitch per 64-byte chunk: the conflict-free fragment layout of the convolution kernels).  Persistent
+// over work units, contiguous unit ranges per XCD; consecutive units share their A rows through that XCD's L2.
+// The epilogue stages the fp32 accumulators through LDS (bias / activation applied) and stores 16-byte coalesced rows.
+#include <stdlib.h>
+#include "common.hpp"
+#include "segk_internal.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int G_PIX = 80;                 // LDS pitch of one row's 64-byte K-chunk
+constexpr int G_BM = 256, G_BN = 128;
+constexpr int G_ACH = G_BM * G_PIX;       // one chunk of the A tile
+constexpr int G_BCH = G_BN * G_PIX;       // one chunk of the weight tile
+constexpr int G_STAGE = 2 * G_ACH + 2 * G_BCH;   // a stage = two chunks (64 K-elements) of both
+constexpr int G_MAINB = 2 * G_STAGE;
+constexpr int G_OP = G_BN * 2 + 16;       // epilogue tile row pitch
+static_assert(G_BM * G_OP <= G_MAINB, "epilogue tile overlays the stage slots");
+
+template <int MODE>   // 0 plain, 1 pixel-shuffle store, 2 un-shuffle gather
+__global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long M = g.M;
+  const int N = g.N;
+  const int NT = N / G_BN;
+  const int MT = (int)((M + G_BM - 1) / G_BM);
+  const int U = MT * NT;
+  const int xcd = blockIdx.x & 7, upx = (U + 7) >> 3;
+  const int GW = gridDim.x >> 3;
+  int u = xcd * upx + (blockIdx.x >> 3);
+  const int u_end = min(U, (xcd + 1) * upx);
+  if (u >= u_end) return;
+  const int nst = g.nchunks >> 1;          // stages per unit (>= 1)
+  const int HW = g.H * g.W;
+
+  if (wave >= 4) {
+    // =============================================== PRODUCERS ===============================================
+    const int ptid = tid - 256;
+    const int within = ptid & 7, pcs = within & 3, cch = within >> 2;
+    const int prow = ptid >> 3;            // 0..31
+    const int a_lds = cch * G_ACH + prow * G_PIX + pcs * 16;
+    const int b_lds = 2 * G_ACH + cch * G_BCH + prow * G_PIX + pcs * 16;
+    u32x4 ra[8], rb[4];
+    long arow[8];                          // element offset of each of this thread's A rows (chunk 0, tap 0)
+    auto unit_rows = [&](int uu) {
+      const long m0 = (long)(uu / NT) * G_BM;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        long m = m0 + prow + 32 * i;
+        m = m < M ? m : M - 1;             // rows past the end read a valid row; they are never stored
+        if (MODE == 2) {
+          const long b = m / HW;
+          const int r = (int)(m - b * HW), y = r / g.W, x = r - y * g.W;
+          arow[i] = (((b * 2 * g.H + 2 * y) * 2 * g.W) + 2 * x) * (long)g.lda;
+        } else {
+          arow[i] = m * (long)g.lda;
+        }
+      }
+    };
+    auto load = [&](int uu, int s) {
+      const int kc = 2 * s + cch;
+      long koff;
+      if (MODE == 2) {
+        const int tap = kc / g.nchA, cc = kc - tap * g.nchA;
+        koff = ((long)(tap >> 1) * 2 * g.W + (tap & 1)) * g.lda + cc * 32 + pcs * 8;
+      } else {
+        koff = (long)kc * 32 + pcs * 8;
+      }
+      const bf16_t* const ab = (const bf16_t*)g.A + koff;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ra[i] = *(const u32x4*)(ab + arow[i]);
+      const int n0 = (uu % NT) * G_BN;
+      const char* const wb = g.w + ((size_t)kc * N + n0 + prow) * 64 + pcs * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = *(const u32x4*)(wb + (size_t)i * 32 * 64);
+    };
+    auto store = [&](int slot) {
+      char* const sb = smem + slot * G_STAGE;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *(u32x4*)(sb + a_lds + i * 32 * G_PIX) = ra[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(u32x4*)(sb + b_lds + i * 32 * G_PIX) = rb[i];
+    };
+    // prologue of the first unit
+    unit_rows(u);
+    load(u, 0);
+    store(0);
+    bool has_next = (u + GW) < u_end;
+    if (nst > 1) load(u, 1);
+    else if (has_next) { unit_rows(u + GW); load(u + GW, 0); }
+    __syncthreads();                                   // B0
+    for (;;) {
+      const int un = u + GW;
+      has_next = un < u_end;
+      for (int s = 0; s < nst; ++s) {
+        if (s + 1 < nst) {
+          store((s + 1) & 1);
+          if (s + 2 < nst) load(u, s + 2);
+          else if (has_next) { unit_rows(un); load(un, 0); }
+        }
+        __syncthreads();
+      }
+      __syncthreads();                                 // E1: consumers staged the output tile
+      // ---- all 512 threads store the tile (shared code below via goto-free duplication)
+      {
+        const long m0 = (long)(u / NT) * G_BM;
+        const int n0 = (u % NT) * G_BN;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int idx = tid + i * 512;
+          const int m = idx >> 4, cc = idx & 15;
+          const long gm = m0 + m;
+          if (gm < M) {
+            const uint4 v = *(const uint4*)(smem + m * G_OP + cc * 16);
+            const int n = n0 + cc * 8;
+            bf16_t* dst;
+            if (MODE == 1) {
+              const int tap = n / g.Cout, co = n - tap * g.Cout;
+              const long b = gm / HW;
+              const int r = (int)(gm - b * HW), y = r / g.W, x = r - y * g.W;
+              dst = (bf16_t*)g.out + ((((b * 2 * g.H + 2 * y + (tap >> 1)) * 2 * g.W) + 2 * x + (tap & 1)) * (long)g.Cout + co);
+            } else {
+              dst = (bf16_t*)g.out + gm * (long)N + n;
+            }
+            *(uint4*)dst = v;
+          }
+        }
+      }
+      if (!has_next) break;
+      __syncthreads();                                 // E2: tile consumed, the stage slots may be rewritten
+      store(0);                                        // next unit's stage 0 (held in registers since the last steps)
+      if (nst > 1) load(un, 1);
+      else if (un + GW < u_end) { unit_rows(un + GW); load(un + GW, 0); }
+      u = un;
+      __syncthreads();                                 // E3
+    }
+    return;
+  }
+
+  // ================================================= CONSUMERS =================================================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  int laneA[4], laneB[2];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) laneA[mf] = ((wm * 4 + mf) * 32 + lr) * G_PIX + lh * 16;
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) laneB[nf] = 2 * G_ACH + ((wn * 2 + nf) * 32 + lr) * G_PIX + lh * 16;
+  f32x16 acc[4][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+  };
+  uint4 fa[2][4], fb[2][2];
+  auto rd = [&](const char* sb, int i, uint4 (&A)[4], uint4 (&Bf)[2]) {
+    const int c = i >> 1, kk = i & 1;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) A[mf] = *(const uint4*)(sb + laneA[mf] + c * G_ACH + kk * 32);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) Bf[nf] = *(const uint4*)(sb + laneB[nf] + c * G_BCH + kk * 32);
+  };
+  zero_acc();
+  __syncthreads();                                     // B0
+  for (;;) {
+    const int un = u + GW;
+    const bool has_next = un < u_end;
+    for (int s = 0; s < nst; ++s) {
+      const char* const sb = smem + (s & 1) * G_STAGE;
+      rd(sb, 0, fa[0], fb[0]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i + 1 < 4) rd(sb, i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < 2; ++nf)
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i & 1][mf]),
+                                                                 __builtin_bit_cast(bf16x8, fb[i & 1][nf]), acc[mf][nf], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+    // ---- epilogue: bias / activation on the fp32 accumulators, tile -> LDS (the stage slots are dead here)
+    {
+      const int n0 = (u % NT) * G_BN;
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        const int n = (wn * 2 + nf) * 32 + lr;
+        const float bv = g.bias ? g.bias[n0 + n] : 0.f;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+          const int mb = (wm * 4 + mf) * 32 + 4 * lh;
+          char* const obase = smem + mb * G_OP + n * 2;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            v[r] = acc[mf][nf][r] + bv;
+            if (g.act) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));      // quick_gelu (CLIPMLP)
+          }
+          float s1 = 0.f, s2 = 0.f;
+          stage_frag<bf16_t>(v, obase, G_OP, s1, s2);
+        }
+      }
+    }
+    zero_acc();
+    __syncthreads();                                   // E1
+    {
+      const long m0 = (long)(u / NT) * G_BM;
+      const int n0 = (u % NT) * G_BN;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 512;
+        const int m = idx >> 4, cc = idx & 15;
+        const long gm = m0 + m;
+        if (gm < M) {
+          const uint4 v = *(const uint4*)(smem + m * G_OP + cc * 16);
+          const int n = n0 + cc * 8;
+          bf16_t* dst;
+          if (MODE == 1) {
+            const int tap = n / g.Cout, co = n - tap * g.Cout;
+            const long b = gm / HW;
+            const int r = (int)(gm - b * HW), y = r / g.W, x = r - y * g.W;
+            dst = (bf16_t*)g.out + ((((b * 2 * g.H + 2 * y + (tap >> 1)) * 2 * g.W) + 2 * x + (tap & 1)) * (long)g.Cout + co);
+          } else {
+            dst = (bf16_t*)g.out + gm * (long)N + n;
+          }
+          *(uint4*)dst = v;
+        }
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();                                   // E2
+    u = un;
+    __syncthreads();                                   // E3
+  }
+}
+
+static int g_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n < 8) n = 256;
+  }
+  return n;
+}
+
+template <int MODE>
+int launch_mode(const GemmArgs& g, hipStream_t st) {
+  auto kern = gemm_pipe_kernel<MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SEGK_FAIL(-3, "gemm_pipe: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  const long U = ((g.M + G_BM - 1) / G_BM) * (g.N / G_BN);
+  const int per_xcd = (int)((U + 7) / 8);
+  int gw = g_num_cus() / 8;
+  if (gw > per_xcd) gw = per_xcd;
+  hipLaunchKernelGGL(kern, dim3(8 * gw), dim3(512), G_MAINB, st, g);
+  SEGK_CHECK_LAUNCH("gemm_pipe");
+  return 0;
+}
+
+}  // namespace
+
+// does the producer/consumer GEMM serve this 1x1-geometry call?  (bf16; whole 64-element K stages that do not
+// straddle ConvTranspose taps; 128-wide channel tiles; enough rows to fill a 256-row tile)
+// Short-K problems are bound by the unit boundary (epilogue + first-stage latency with one workgroup per CU) and stay
+// on the generic kernel (two 4-wave workgroups per CU): threshold in 32-element chunks, per mode; the environment
+// variable SEGK_GEMM_PIPE_MIN_CHUNKS overrides all three (kernel A/B measurements: tools/kbench.py convt).
+static int min_chunks(int mode) {
+  static int env = -2;
+  if (env == -2) {
+    const char* e = getenv("SEGK_GEMM_PIPE_MIN_CHUNKS");
+    env = e ? atoi(e) : -1;
+  }
+  if (env >= 0) return env;
+  // same-box A/B at the U-Net's ConvTranspose shapes (B = 32): pixel-shuffle store K = 1024 / 512 / 256 / 128:
+  // 55 / 71 / 93 / 151 us here against 66 / 74 / 83 / 139 us generic; un-shuffle gather K = 2048 / 1024 / 512 / 256:
+  // 51 / 54 / 64 / 100 against 69 / 70 / 72 / 110
+  return mode == 1 ? 16 : 8;
+}
+
+int segk_gemm_pipe_ok(long M, int nchunks, int nchA, int N, int cout_shuffle, int mode) {
+  if (nchunks < 2 || nchunks < min_chunks(mode) || (nchunks & 1) || N % G_BN != 0 || M < 128) return 0;
+  if (mode == 2 && (nchA & 1)) return 0;
+  if (mode == 1 && (cout_shuffle % 8 != 0)) return 0;
+  return 1;
+}
+
+int segk_gemm_pipe_launch(const GemmArgs& g, int mode, hipStream_t st) {
+  SEGK_REQUIRE(g.A && g.w && g.out && g.M > 0, "gemm_pipe: null pointer / empty problem");
+  SEGK_REQUIRE(segk_gemm_pipe_ok(g.M, g.nchunks, g.nchA, g.N, g.Cout, mode), "gemm_pipe: unsupported shape");
+  SEGK_REQUIRE(g.M * 4 < 2147483647LL * 64, "gemm_pipe: row count too large");
+  if (mode == 1) return launch_mode<1>(g, st);
+  if (mode == 2) return launch_mode<2>(g, st);
+  return launch_mode<0>(g, st);
+}

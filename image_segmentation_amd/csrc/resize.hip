@@ -92,6 +92,73 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
   }
 }
 
+// Separable backward for large up-sampling factors (the CLIP skips go 14x14 -> up to 224x224: a 2-D gather walks
+// ~(3r)^2 candidate output pixels per input pixel, r = 16).  Pass 1 reduces along x into fp32 [B,OH,IW,C], pass 2 along
+// y: each pass walks ~3r candidates, the output gradient is read about twice, and the result is deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_x_kernel(const T* __restrict__ dy, float* __restrict__ tmp, int B, int IW,
+                                                             int OH, int OW, int C) {
+  using E = ET<T>;
+  const int CV = C / E::VEC;
+  const float sw = (float)IW / (float)OW, rw = (float)OW / (float)IW;
+  const long total = (long)B * OH * IW * CV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ix = (int)(p % IW);
+    const long row = p / IW;                       // b * OH + oy
+    int lo = (int)floorf(((float)ix - 1.f) * rw) - 1, hi = (int)ceilf(((float)ix + 2.f) * rw) + 1;
+    lo = max(lo, 0); hi = min(hi, OW - 1);
+    float acc[E::VEC];
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) acc[j] = 0.f;
+    for (int ox = lo; ox <= hi; ++ox) {
+      int x0, x1; float lx;
+      src_index(ox, sw, IW, x0, x1, lx);
+      const float w = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+      if (w == 0.f) continue;
+      float g[E::VEC];
+      unpack16<T>(*(const uint4*)(dy + ((size_t)row * OW + ox) * C + cv * E::VEC), g);
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) acc[j] = fmaf(w, g[j], acc[j]);
+    }
+    float* dst = tmp + ((size_t)row * IW + ix) * C + cv * E::VEC;
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) dst[j] = acc[j];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_y_kernel(const float* __restrict__ tmp, T* __restrict__ dx, int B, int IH,
+                                                             int IW, int OH, int C) {
+  using E = ET<T>;
+  const int CV = C / E::VEC;
+  const float sh = (float)IH / (float)OH, rh = (float)OH / (float)IH;
+  const long total = (long)B * IH * IW * CV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ix = (int)(p % IW); p /= IW;
+    const int iy = (int)(p % IH);
+    const int b = (int)(p / IH);
+    int lo = (int)floorf(((float)iy - 1.f) * rh) - 1, hi = (int)ceilf(((float)iy + 2.f) * rh) + 1;
+    lo = max(lo, 0); hi = min(hi, OH - 1);
+    float acc[E::VEC];
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) acc[j] = 0.f;
+    for (int oy = lo; oy <= hi; ++oy) {
+      int y0, y1; float ly;
+      src_index(oy, sh, IH, y0, y1, ly);
+      const float w = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (w == 0.f) continue;
+      const float* src = tmp + (((size_t)b * OH + oy) * IW + ix) * C + cv * E::VEC;
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) acc[j] = fmaf(w, src[j], acc[j]);
+    }
+    *(uint4*)(dx + (((size_t)b * IH + iy) * IW + ix) * C + cv * E::VEC) = pack16<T>(acc);
+  }
+}
+
 }  // namespace
 
 extern "C" int segk_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,
@@ -109,10 +176,25 @@ extern "C" int segk_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, 
   return 0;
 }
 
-extern "C" int segk_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,
-                                 segk_stream_t s) {
+extern "C" int segk_bilinear_bwd(const void* dy, void* dx, float* scratch, int B, int IH, int IW, int OH, int OW, int Cp,
+                                 int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dy && dx && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && Cp > 0 && Cp % 32 == 0, "bilinear_bwd: bad arguments");
   const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
+  if (scratch) {   // separable two-pass form: scratch holds B*OH*IW*Cp floats
+    hipStream_t st2 = (hipStream_t)s;
+    long g1 = ((long)B * OH * IW * (Cp / vec) + 255) / 256, g2 = ((long)B * IH * IW * (Cp / vec) + 255) / 256;
+    if (g1 > 16384) g1 = 16384;
+    if (g2 > 16384) g2 = 16384;
+    if (dtype == SEGK_DT_BF16) {
+      hipLaunchKernelGGL(bilinear_bwd_x_kernel<bf16_t>, dim3((int)g1), dim3(256), 0, st2, (const bf16_t*)dy, scratch, B, IW, OH, OW, Cp);
+      hipLaunchKernelGGL(bilinear_bwd_y_kernel<bf16_t>, dim3((int)g2), dim3(256), 0, st2, scratch, (bf16_t*)dx, B, IH, IW, OH, Cp);
+    } else {
+      hipLaunchKernelGGL(bilinear_bwd_x_kernel<float>, dim3((int)g1), dim3(256), 0, st2, (const float*)dy, scratch, B, IW, OH, OW, Cp);
+      hipLaunchKernelGGL(bilinear_bwd_y_kernel<float>, dim3((int)g2), dim3(256), 0, st2, scratch, (float*)dx, B, IH, IW, OH, Cp);
+    }
+    SEGK_CHECK_LAUNCH("bilinear_bwd");
+    return 0;
+  }
   long g = ((long)B * IH * IW * (Cp / vec) + 255) / 256;
   if (g > 8192) g = 8192;
   hipStream_t st = (hipStream_t)s;

@@ -43,3 +43,21 @@ struct WgradArgs {
   int S;                // split-K factor over spatial tiles
 };
 int segk_wgrad_launch(const WgradArgs& a, int geo, int dtype, hipStream_t st);
+
+// producer/consumer bf16 GEMM of the 1x1 geometry (gemm.hip)
+struct GemmArgs {
+  const void* A;        // rows [M][lda] bf16 (un-shuffle gather: [B,2H,2W,lda])
+  const char* w;        // packed weights [nchunks][N][32] bf16
+  const float* bias;    // optional per-N bias
+  void* out;            // [M][N] bf16 (pixel-shuffle store: [B,2H,2W,Cout])
+  long M;               // rows (B*H*W)
+  int N;                // multiple of 128
+  int nchunks;          // K / 32 (even)
+  int nchA;             // un-shuffle gather: chunks per tap (K = 4 taps x nchA chunks)
+  int lda;              // elements per A row
+  int H, W;             // input grid of the ConvTranspose modes
+  int Cout;             // pixel-shuffle store: channels per tap (N = 4*Cout)
+  int act;              // 1 = quick_gelu on (acc + bias)
+};
+int segk_gemm_pipe_ok(long M, int nchunks, int nchA, int N, int cout_shuffle, int mode);   // mode 0 plain, 1 shuffle, 2 un-shuffle
+int segk_gemm_pipe_launch(const GemmArgs& g, int mode, hipStream_t st);

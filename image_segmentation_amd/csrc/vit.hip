@@ -12,12 +12,14 @@
 //                    patch_embedding weight), so the patch projection is a GEMM
 //   vit_embed_ln     class token + patch tokens + position embedding, pre-LayerNorm -> fp32 residual stream
 //   add_layernorm    h += delta (a GEMM output); out = LayerNorm(h) in the compute dtype (one wave per token)
-//   attention        per (image, head, 64-query block): softmax(q k^T * scale) v, exact fp32 arithmetic on the
-//                    VALU with K/V of the head resident in LDS; 4 waves split the keys and merge their online-
-//                    softmax partials through LDS
+//   attention        bf16, head_dim 64: flash-style on the matrix cores (attention_mfma_kernel below); fp32 parity mode
+//                    and other head sizes: per (image, head, 64-query block) softmax(q k^T * scale) v in exact fp32
+//                    arithmetic on the VALU with K/V of the head resident in LDS, 4 waves splitting the keys and
+//                    merging their online-softmax partials through LDS
 //   vit_tokens_to_grid   drop CLS, residual stream -> NHWC feature grid [B,G,G,D] (clipunet.py:48-63)
 // The residual stream stays fp32 in both compute modes (it is 2.4 MB per image batch of 16); GEMM operands are
 // the compute dtype.
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/segk.h"
 
@@ -258,6 +260,139 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   }
 }
 
+// ---- attention on the matrix cores (bf16, head_dim 64) ---------------------------------------------------------
+// grid (ceil(T/128), B*heads), 256 threads: each wave owns 32 queries and walks the keys in blocks of 32, flash style.
+//   S^T block [32 keys x 32 queries] = K_blk . Q^T      4 x MFMA 32x32x16 (K rows from LDS, the Q fragment in registers)
+//   online softmax per query column: the 32x32 accumulator layout gives a lane 16 keys of ONE query, the other half-wave
+//   holds the other 16 (one __shfl_xor for the block maximum); exp2 with the scale folded into the exponent
+//   O^T [64 x 32 queries] += V^T_blk . P^T              4 x MFMA: the bf16-packed P registers ARE the B fragment (the k
+//   slots of a lane are its own 8 keys), the A fragment comes from V staged TRANSPOSED in LDS (two 8-byte reads)
+// LDS: K [Tp][144 B] + V^T [64][Tp*2 + 16 B] (Tp = T rounded up to 32; padding keys are zero and masked).
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int Tn,
+                                                             int heads, int ldq, int ldo, float scale) {
+  constexpr int HD = 64, KP = 144;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tp = (Tn + 31) & ~31;
+  const int VP = Tp * 2 + 16;
+  char* const Ks = smem;
+  char* const Vt = smem + (size_t)Tp * KP;
+  const int bh = blockIdx.y, b = bh / heads, hh = bh % heads;
+  const int D = heads * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const bf16_t* const base = qkv + (size_t)b * Tn * ldq + hh * HD;
+  // ---- stage K (rows) and V (transposed) of this head
+  for (int i = threadIdx.x; i < Tp * 8; i += 256) {
+    const int j = i >> 3, c = i & 7;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
+    if (j < Tn) {
+      kv = *(const uint4*)(base + (size_t)j * ldq + D + c * 8);
+      vv = *(const uint4*)(base + (size_t)j * ldq + 2 * D + c * 8);
+    }
+    *(uint4*)(Ks + j * KP + c * 16) = kv;
+    const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      *(uint16_t*)(Vt + (c * 8 + e) * VP + j * 2) = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+  }
+  // ---- this wave's queries: Q fragment (B operand) straight from global memory
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int qi = q0 + lr;
+  const int qc = qi < Tn ? qi : Tn - 1;
+  uint4 qf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qf[j] = *(const uint4*)(base + (size_t)qc * ldq + j * 16 + lh * 8);
+  __syncthreads();
+  if (q0 >= Tn) return;                              // a wave without queries (after the only barrier)
+  const float c2 = scale * 1.44269504088896341f;     // exp(x*scale) = exp2(x*c2)
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  const int nkb = Tp >> 5;
+  for (int kb = 0; kb < nkb; ++kb) {
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    const char* const kr = Ks + (kb * 32 + lr) * KP + lh * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint4 kf = *(const uint4*)(kr + j * 32);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[j]), sacc, 0, 0, 0);
+    }
+    const int kbase = kb * 32 + 4 * lh;
+    float bm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kbase + (r & 3) + 8 * (r >> 2);
+      sacc[r] = key < Tn ? sacc[r] : -INFINITY;
+      bm = fmaxf(bm, sacc[r]);
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    const float mn = fmaxf(m, bm);                   // finite from the first block on (key 0 is always valid)
+    const float corr = exp2f((m - mn) * c2);
+    m = mn;
+    l *= corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+    uint32_t pk[8];
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = exp2f((sacc[r] - mn) * c2), p1 = exp2f((sacc[r + 1] - mn) * c2);
+      ps += p0 + p1;
+      pk[r >> 1] = pack_bf16x2(p0, p1);
+    }
+    l += ps;
+    // P^T fragments: k slots of this lane = its keys of registers 0..7 (first MFMA) and 8..15 (second)
+    const uint4 pb0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), pb1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    // V^T fragments: row d = dblk*32 + lr, keys kbase + {0..3, 8..11} and kbase + {16..19, 24..27}
+    const char* const v0 = Vt + lr * VP + kbase * 2;
+    const char* const v1 = v0 + 32 * VP;
+    uint2 a, c;
+    a = *(const uint2*)(v0); c = *(const uint2*)(v0 + 16);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, c.x, c.y)),
+                                                 __builtin_bit_cast(bf16x8, pb0), o0, 0, 0, 0);
+    a = *(const uint2*)(v0 + 32); c = *(const uint2*)(v0 + 48);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, c.x, c.y)),
+                                                 __builtin_bit_cast(bf16x8, pb1), o0, 0, 0, 0);
+    a = *(const uint2*)(v1); c = *(const uint2*)(v1 + 16);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, c.x, c.y)),
+                                                 __builtin_bit_cast(bf16x8, pb0), o1, 0, 0, 0);
+    a = *(const uint2*)(v1 + 32); c = *(const uint2*)(v1 + 48);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, c.x, c.y)),
+                                                 __builtin_bit_cast(bf16x8, pb1), o1, 0, 0, 0);
+  }
+  l += __shfl_xor(l, 32);                            // both half-waves applied the same corrections: plain sum
+  const float inv = 1.f / l;
+  if (qi < Tn) {
+    bf16_t* const dst = ctx + ((size_t)b * Tn + qi) * ldo + hh * HD + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                    // registers 4g..4g+3 = head dims 4*lh + 8g + {0..3} (+32 for o1)
+      *(uint2*)(dst + 8 * g) = make_uint2(pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                                          pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+      *(uint2*)(dst + 32 + 8 * g) = make_uint2(pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                                               pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+    }
+  }
+}
+
+int launch_attention_mfma(const void* qkv, void* ctx, int B, int Tn, int heads, int ldq, int ldo, float scale, hipStream_t st) {
+  const int Tp = (Tn + 31) & ~31;
+  const size_t lds = (size_t)Tp * 144 + (size_t)64 * (Tp * 2 + 16);
+  SEGK_REQUIRE(lds <= 160 * 1024, "attention: %d tokens do not fit the 160 KiB LDS (%zu bytes)", Tn, lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SEGK_FAIL(-3, "attention: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attention_mfma_kernel, dim3(cdiv(Tn, 128), B * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)ctx,
+                     Tn, heads, ldq, ldo, scale);
+  SEGK_CHECK_LAUNCH("attention_mfma");
+  return 0;
+}
+
 template <typename T, int HD>
 int launch_attention(const void* qkv, void* ctx, int B, int Tn, int heads, int ldq, int ldo, float scale, hipStream_t st) {
   const int Tp = (Tn + 3) & ~3;
@@ -341,6 +476,8 @@ extern "C" int segk_attention(const void* qkv, void* ctx, int B, int T, int head
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "attention: bad dtype");
   SEGK_REQUIRE((long)B * heads <= 65535, "attention: B*heads exceeds the grid limit");
   hipStream_t st = (hipStream_t)s;
+  if (dtype == SEGK_DT_BF16 && head_dim == 64 && !getenv("SEGK_ATTENTION_VALU"))   // matrix-core kernel
+    return launch_attention_mfma(qkv, ctx, B, T, heads, ldq, ldo, scale, st);
   if (dtype == SEGK_DT_BF16)
     return head_dim == 64 ? launch_attention<bf16_t, 64>(qkv, ctx, B, T, heads, ldq, ldo, scale, st)
                           : launch_attention<bf16_t, 32>(qkv, ctx, B, T, heads, ldq, ldo, scale, st);

@@ -720,7 +720,9 @@ class BilinearFn(torch.autograd.Function):
         d_t, pd, _ = _raw(dy, dtype)
         dx = torch.empty((B, IH, IW, Cp), dtype=dtype, device=dy.device)
         with _span("bilinear_bwd", 0.0, B * (IH * IW + OH * OW) * C * _es(dtype)):
-            _lib.call("segk_bilinear_bwd", pd, dx.data_ptr(), B, IH, IW, OH, OW, Cp, _DT[dtype], _stream())
+            # separable two-pass form when the map grows by more than 2x (the CLIP skips: 14 -> 28..224)
+            tmp = _f32(B * OH * IW * Cp, dy.device) if OH * OW > 4 * IH * IW else None
+            _lib.call("segk_bilinear_bwd", pd, dx.data_ptr(), _p(tmp), B, IH, IW, OH, OW, Cp, _DT[dtype], _stream())
         return act_view(dx, C), None, None
 
 

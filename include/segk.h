@@ -125,7 +125,9 @@ int segk_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int H, i
  * x [B,IH,IW,Cp] -> y [B,OH,OW,Cp]; backward is a deterministic gather dy -> dx */
 int segk_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,
                       segk_stream_t s);
-int segk_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,
+/* scratch: B*OH*IW*Cp floats for the separable two-pass form (x then y; about 3x the up-sampling factor of work per
+ * element instead of its square), or NULL for the single-pass 2-D gather */
+int segk_bilinear_bwd(const void* dy, void* dx, float* scratch, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,
                       segk_stream_t s);
 
 /* ---- CLIP vision transformer, frozen feature extractor (clip/clipunet.py:25-46,48-63 drive transformers'

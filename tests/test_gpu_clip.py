@@ -29,7 +29,8 @@ def close(a, b, rtol, atol, msg=""):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 32, 14, 14, 28, 28), (1, 64, 14, 14, 224, 224), (2, 40, 3, 5, 6, 10), (1, 32, 7, 7, 10, 13)])
+@pytest.mark.parametrize("case", [(2, 32, 14, 14, 28, 28), (1, 64, 14, 14, 224, 224), (2, 40, 3, 5, 6, 10), (1, 32, 7, 7, 10, 13),
+                                  (2, 32, 14, 14, 56, 56), (1, 32, 5, 9, 23, 40), (1, 96, 14, 14, 112, 112)])
 def test_bilinear(seg, dtype, case):
     from image_segmentation_amd import ops
     B, C, IH, IW, OH, OW = case

@@ -305,3 +305,35 @@ def test_confusion(ops):
         for l in range(4):
             ref[p, l] = ((hard == p) & (Y == l)).sum()
     assert torch.equal(M, ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 128, 64, 16, 16), (1, 64, 32, 8, 8), (2, 256, 128, 12, 20), (1, 96, 64, 16, 16),
+                                  (3, 64, 128, 10, 14)])
+def test_convt2x2_forward_and_data_gradient(ops, dtype, case):
+    """ConvTranspose2d(k=2,s=2) as GEMM + pixel-shuffle store and its data gradient as an un-shuffle gather GEMM
+    (reference unet/unet.py:59): the long-K shapes run the producer/consumer GEMM (gemm.hip), short or ragged ones the
+    generic streaming kernel; both against F.conv_transpose2d / its autograd."""
+    from image_segmentation_amd import _lib
+    B, Cin, Cout, H, W = case
+    x0 = fill((B, Cin, H, W), 1, -1, 1).to(dtype).float()
+    w0 = (fill((Cin, Cout, 2, 2), 2, -1, 1) / Cin ** 0.5).to(dtype).float()
+    b0 = fill((Cout,), 3, -0.5, 0.5)
+    g0 = fill((B, Cout, 2 * H, 2 * W), 4, -1, 1).to(dtype).float()
+    x = x0.clone().requires_grad_(True)
+    y = F.conv_transpose2d(x, w0, b0, stride=2)
+    y.backward(g0)
+    s = torch.cuda.current_stream().cuda_stream
+    xa = ops.to_act(dev(x0), dtype)
+    px, _ = ops.act_info(xa, dtype)
+    wf, wd = ops.pack_convt(dev(w0), dtype, 0), ops.pack_convt(dev(w0), dtype, 1)
+    b4 = dev(b0).repeat(4).contiguous()
+    out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=dtype, device="cuda")
+    _lib.call("segk_convt2x2_fwd", px, wf.data_ptr(), b4.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, ops._DT[dtype], s)
+    got = back(out.permute(0, 3, 1, 2))
+    assert (got - y.detach()).abs().max() < tol(dtype, Cin)
+    ga = ops.to_act(dev(g0), dtype)
+    pg, _ = ops.act_info(ga, dtype)
+    dx = torch.empty((B, H, W, Cin), dtype=dtype, device="cuda")
+    _lib.call("segk_convt2x2_dgrad", pg, wd.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, ops._DT[dtype], s)
+    assert (back(dx.permute(0, 3, 1, 2)) - x.grad).abs().max() < tol(dtype, 4 * Cout)

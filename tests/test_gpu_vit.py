@@ -40,7 +40,9 @@ def _stream():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,K,N,act", [(48, 64, 128, 0), (400, 768, 256, 1), (3152, 96, 64, 1), (16, 32, 32, 0)])
+@pytest.mark.parametrize("M,K,N,act", [(48, 64, 128, 0), (400, 768, 256, 1), (3152, 96, 64, 1), (16, 32, 32, 0),
+                                       (3152, 768, 2304, 0), (256, 64, 128, 0), (1008, 128, 384, 1), (144, 3072, 768, 0),
+                                       (2064, 192, 128, 0)])
 def test_linear_gemm(seg, dtype, M, K, N, act):
     from image_segmentation_amd import _lib, ops
     x = fill((M, K), 1, -1, 1).to(dtype).float()
