@@ -115,14 +115,35 @@ def _raw(t, dtype):
 
 # ------------------------------------------------------------------------------------------------
 # packed-weight cache (parameters stay fp32 OIHW/IOHW: the source of truth for state_dict/optimizer)
+# Optimizer steps invalidate every packed copy of a trainable parameter.  The autograd version counter alone is not
+# enough: fused optimizers (torch.optim.AdamW(fused=True), torch._fused_adamw_) update parameters in place WITHOUT
+# moving `param._version`, so a global post-step hook counts optimizer steps as well.
+_OPT_EPOCH = [0]
+
+
+def _on_optimizer_step(optimizer, args, kwargs):
+    _OPT_EPOCH[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(_on_optimizer_step)
+
+
+def invalidate_packed_weights():
+    """Call after changing parameters behind autograd's back (e.g. writing through `.data`)."""
+    _OPT_EPOCH[0] += 1
+
+
 class PackCache:
-    """Re-packs a parameter into the MFMA layout only when its autograd version counter moved."""
+    """Re-packs a parameter into the MFMA layout when its autograd version counter moved, when it was re-allocated,
+    or (trainable parameters) when any optimizer has stepped since the copy was made."""
 
     def __init__(self):
         self._c = {}
 
     def get(self, key, param, builder):
-        ver = (param._version, param.data_ptr(), param.device)
+        ver = (param._version, param.data_ptr(), param.device, _OPT_EPOCH[0] if param.requires_grad else -1)
         hit = self._c.get(key)
         if hit is None or hit[0] != ver:
             hit = (ver, builder())

@@ -242,3 +242,27 @@ def test_unet_bf16_tracks_fp32_mode_across_shapes(seg, shape):
             # pixels on the small images here: 30 %
             rel = 0.08 if dim > 1 else 0.30
             assert abs(nb - nf) <= rel * nf + 1e-4, (n, nf, nb)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_optimizer_steps_invalidate_packed_weights(seg, dtype):
+    """torch.optim.AdamW(fused=True) updates parameters without moving their autograd version counter; the packed
+    MFMA copies must still follow every optimizer step (forward, data-gradient and ConvTranspose packs)."""
+    seg.set_compute_dtype(dtype)
+    m = seg.unet(3, 3); fill_module(m, 1000); m.cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.01, fused=True)
+    X = fill((2, 3, 32, 32), 1, 0, 1).cuda(); Y = labels((2, 32, 32), 2, 3).cuda()
+    loss_fn = seg.CrossEntropyLoss()
+    for _ in range(3):
+        opt.zero_grad()
+        loss_fn(m(X), Y).backward()
+        opt.step()
+    opt.zero_grad()
+    fresh = seg.unet(3, 3).cuda().train()
+    fresh.load_state_dict(m.state_dict())
+    la = m(X); lb = fresh(X)                               # same parameters, packs made before / after the steps
+    assert torch.equal(la, lb)
+    la.sum().backward(); lb.sum().backward()
+    for (n, a), (_, b) in zip(m.named_parameters(), fresh.named_parameters()):
+        assert torch.equal(a.grad, b.grad), n
+    seg.set_compute_dtype(torch.bfloat16)
