@@ -80,6 +80,38 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restri
   }
 }
 
+// Both packed layouts of a 3x3 weight in ONE pass (they are re-made after every optimizer step: 35 + 8 packs per U-Net
+// step otherwise).  A block owns a 32 (output channels) x 32 (padded input channels) x 9 tile: coalesced fp32 reads
+// into LDS, then per tap one contiguous 32 x 32 block of the forward layout and one of the data-gradient layout.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv3x3_both_kernel(const float* __restrict__ w, T* __restrict__ df,
+                                                                T* __restrict__ dd, int Cout, int CA, int CB, int Coutp,
+                                                                int CAp, int CBp) {
+  constexpr int CH = ET<T>::CH;
+  __shared__ float tile[32][32 * 9 + 1];
+  const int Cin = CA + CB, Cinp = CAp + CBp;
+  const int kp0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  for (int idx = threadIdx.x; idx < 32 * 288; idx += 256) {
+    const int j = idx / 288, r = idx - j * 288, kk = r / 9, tap = r - kk * 9;
+    const int ci = dual_map(kp0 + kk, CA, CAp, CB, CBp);
+    float v = 0.f;
+    if (ci >= 0 && co0 + j < Cout) v = w[((long)(co0 + j) * Cin + ci) * 9 + tap];
+    tile[j][r] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 9 * 1024; idx += 256) {
+    const int tap = idx >> 10, r = idx & 1023;
+    {   // forward: K = input channels (kp), N = output channels
+      const int j = r >> 5, kk = r & 31, kp = kp0 + kk;
+      df[(((long)(kp / CH) * 9 + tap) * Coutp + co0 + j) * CH + kp % CH] = from_float<T>(tile[j][kk * 9 + tap]);
+    }
+    if (dd) {   // data gradient: K = output channels, N = input channels, taps flipped
+      const int kk = r >> 5, j = r & 31, co = co0 + j;
+      dd[(((long)(co / CH) * 9 + tap) * Cinp + kp0 + kk) * CH + co % CH] = from_float<T>(tile[j][kk * 9 + (8 - tap)]);
+    }
+  }
+}
+
 // ConvTranspose2d(k=2,s=2) weight [Cin][Cout][2][2] -> packed.
 //  mode 0 (forward GEMM, N = q*Coutp + co, K = ci):         dst[kc][0][n][j] = W[ci=kc*CH+j][co][q]
 //  mode 1 (data grad, K = q*Coutp + co via un-shuffle):     dst[kc][0][n=ci][j] = W[ci][co][q], kc = q*(Coutp/CH)+cc
@@ -196,6 +228,23 @@ int segk_pack_conv_weight_impl(const float* w, void* dst, int Cout, int CA, int 
     hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, w, (float*)dst, Cout, CA,
                        CB, Coutp, CAp, CBp, taps, mode);
   SEGK_CHECK_LAUNCH("pack_conv_weight");
+  return 0;
+}
+
+int segk_pack_conv3x3_both_impl(const float* w, void* dst_fwd, void* dst_dgrad, int Cout, int CA, int CB, int Coutp, int CAp,
+                                 int CBp, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(w && dst_fwd && Cout > 0 && CA > 0 && CB >= 0, "pack_conv3x3_both: bad arguments");
+  SEGK_REQUIRE(Coutp >= Cout && CAp >= CA && CBp >= CB && Coutp % 32 == 0 && CAp % 32 == 0 && CBp % 32 == 0 &&
+                   (CBp == 0) == (CB == 0),
+               "pack_conv3x3_both: bad padding");
+  const dim3 grid((CAp + CBp) / 32, Coutp / 32);
+  if (dtype == SEGK_DT_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_both_kernel<bf16_t>, grid, dim3(256), 0, st, w, (bf16_t*)dst_fwd, (bf16_t*)dst_dgrad, Cout,
+                       CA, CB, Coutp, CAp, CBp);
+  else
+    hipLaunchKernelGGL(pack_conv3x3_both_kernel<float>, grid, dim3(256), 0, st, w, (float*)dst_fwd, (float*)dst_dgrad, Cout, CA,
+                       CB, Coutp, CAp, CBp);
+  SEGK_CHECK_LAUNCH("pack_conv3x3_both");
   return 0;
 }
 

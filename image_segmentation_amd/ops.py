@@ -142,6 +142,17 @@ class PackCache:
     def __init__(self):
         self._c = {}
 
+    def get_pair(self, key_a, key_b, param, builder):
+        """Two packed copies made by one builder call (returns the first; the second is served by get(key_b))."""
+        ver = (param._version, param.data_ptr(), param.device, _OPT_EPOCH[0] if param.requires_grad else -1)
+        hit = self._c.get(key_a)
+        if hit is None or hit[0] != ver:
+            a, b = builder()
+            hit = (ver, a)
+            self._c[key_a] = hit
+            self._c[key_b] = (ver, b)
+        return hit[1]
+
     def get(self, key, param, builder):
         ver = (param._version, param.data_ptr(), param.device, _OPT_EPOCH[0] if param.requires_grad else -1)
         hit = self._c.get(key)
@@ -161,6 +172,20 @@ def pack_conv(w, CA, CB, dtype, mode, taps=9):
     _lib.call("segk_pack_conv_weight", wf.data_ptr(), dst.data_ptr(), Cout, CA, CB, Coutp, CAp, CBp, taps, mode,
               _DT[dtype], _stream())
     return dst
+
+
+def pack_conv_both(w, CA, CB, dtype):
+    """Forward and data-gradient layouts of a 3x3 weight in one kernel pass -> (fwd, dgrad)."""
+    Cout = w.shape[0]
+    Coutp, CAp, CBp = pad32(Cout), pad32(CA), (pad32(CB) if CB else 0)
+    n = (CAp + CBp) * 9 * Coutp
+    both = torch.empty((2 * n,), dtype=dtype, device=w.device)
+    wf = w.detach()
+    if wf.dtype != torch.float32 or not wf.is_contiguous():
+        wf = wf.float().contiguous()
+    _lib.call("segk_pack_conv3x3_both", wf.data_ptr(), both.data_ptr(), both[n:].data_ptr(), Cout, CA, CB, Coutp, CAp, CBp,
+              _DT[dtype], _stream())
+    return both[:n], both[n:]
 
 
 def pack_convt(w, dtype, mode):
@@ -397,8 +422,12 @@ class DoubleConvFn(torch.autograd.Function):
         bn1, bn2 = mod.bn_modules()
         xa_t, pA, CAp = _raw(xa, dtype)
         xb_t, pB, CBp = (None, 0, 0) if xb is None else _raw(xb, dtype)
-        w1p = mod.cache.get(("w1f", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 0))
-        w2p = mod.cache.get(("w2f", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 0))
+        if training and any(ctx.needs_input_grad):     # a backward will follow: both layouts in one pass per weight
+            w1p = mod.cache.get_pair(("w1f", dtype), ("w1d", dtype), w1, lambda: pack_conv_both(w1, CA, CB, dtype))
+            w2p = mod.cache.get_pair(("w2f", dtype), ("w2d", dtype), w2, lambda: pack_conv_both(w2, Cout, 0, dtype))
+        else:
+            w1p = mod.cache.get(("w1f", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 0))
+            w2p = mod.cache.get(("w2f", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 0))
         tiles1 = _lib.query("segk_conv_tiles", B, H, W, CAp + CBp, Coutp, _DT[dtype])
         tiles2 = _lib.query("segk_conv_tiles", B, H, W, Coutp, Coutp, _DT[dtype])
         P = B * H * W

@@ -45,6 +45,10 @@ int segk_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, i
  * in/out swapped).  taps = 9 (3x3) or 1 (1x1).  dst holds (CAp+CBp)*taps*Coutp elements. */
 int segk_pack_conv_weight(const float* w, void* dst, int Cout, int CA, int CB, int Coutp, int CAp, int CBp,
                           int taps, int mode, int dtype, segk_stream_t s);
+/* 3x3 weights: the forward (mode 0) and data-gradient (mode 1) layouts of segk_pack_conv_weight in one pass over the
+ * fp32 parameter (training re-packs after every optimizer step); dst_dgrad may be NULL */
+int segk_pack_conv3x3_both(const float* w, void* dst_fwd, void* dst_dgrad, int Cout, int CA, int CB, int Coutp, int CAp,
+                           int CBp, int dtype, segk_stream_t s);
 /* ConvTranspose2d(k=2,s=2) weight IOHW fp32 [Cin][Cout][2][2] -> MFMA layout; mode 0 forward, 1 data-gradient */
 int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cinp, int Coutp, int mode, int dtype,
                            segk_stream_t s);

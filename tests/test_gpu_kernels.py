@@ -337,3 +337,14 @@ def test_convt2x2_forward_and_data_gradient(ops, dtype, case):
     dx = torch.empty((B, H, W, Cin), dtype=dtype, device="cuda")
     _lib.call("segk_convt2x2_dgrad", pg, wd.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, ops._DT[dtype], s)
     assert (back(dx.permute(0, 3, 1, 2)) - x.grad).abs().max() < tol(dtype, 4 * Cout)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(64, 3, 0), (8, 3, 0), (64, 64, 0), (128, 64, 64), (70, 40, 0), (32, 20, 50)])
+def test_pack_both_layouts_matches_single_packs(ops, dtype, case):
+    """The one-pass forward + data-gradient pack (segk_pack_conv3x3_both) against the per-mode pack, bit for bit."""
+    Cout, CA, CB = case
+    w = dev(fill((Cout, CA + CB, 3, 3), 1, -1, 1))
+    f, d = ops.pack_conv_both(w, CA, CB, dtype)
+    assert torch.equal(f, ops.pack_conv(w, CA, CB, dtype, 0))
+    assert torch.equal(d, ops.pack_conv(w, CA, CB, dtype, 1))
