@@ -87,27 +87,44 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_conv3x3_both_kernel(const float* __restrict__ w, T* __restrict__ df,
                                                                 T* __restrict__ dd, int Cout, int CA, int CB, int Coutp,
                                                                 int CAp, int CBp) {
-  constexpr int CH = ET<T>::CH;
+  using E = ET<T>;
+  constexpr int CH = E::CH, VEC = E::VEC, VPR = 32 / VEC;     // 16-byte vectors per 32-element row
   __shared__ float tile[32][32 * 9 + 1];
   const int Cin = CA + CB, Cinp = CAp + CBp;
   const int kp0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-  for (int idx = threadIdx.x; idx < 32 * 288; idx += 256) {
-    const int j = idx / 288, r = idx - j * 288, kk = r / 9, tap = r - kk * 9;
-    const int ci = dual_map(kp0 + kk, CA, CAp, CB, CBp);
-    float v = 0.f;
-    if (ci >= 0 && co0 + j < Cout) v = w[((long)(co0 + j) * Cin + ci) * 9 + tap];
-    tile[j][r] = v;
+  const int ci0 = dual_map(kp0, CA, CAp, CB, CBp), ci31 = dual_map(kp0 + 31, CA, CAp, CB, CBp);
+  if (ci0 >= 0 && ci31 == ci0 + 31 && co0 + 32 <= Cout && (Cin & 3) == 0 && (ci0 & 3) == 0) {
+    // whole tile inside the parameter: every output channel's 32 x 9 floats are contiguous and 16-byte aligned
+    for (int idx = threadIdx.x; idx < 32 * 72; idx += 256) {
+      const int j = idx / 72, q = idx - j * 72;
+      const float4 v = *(const float4*)(w + ((long)(co0 + j) * Cin + ci0) * 9 + q * 4);
+      float* t = &tile[j][q * 4];
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < 32 * 288; idx += 256) {
+      const int j = idx / 288, r = idx - j * 288, kk = r / 9;
+      const int ci = dual_map(kp0 + kk, CA, CAp, CB, CBp);
+      float v = 0.f;
+      if (ci >= 0 && co0 + j < Cout) v = w[((long)(co0 + j) * Cin + ci) * 9 + (r - kk * 9)];
+      tile[j][r] = v;
+    }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 9 * 1024; idx += 256) {
-    const int tap = idx >> 10, r = idx & 1023;
-    {   // forward: K = input channels (kp), N = output channels
-      const int j = r >> 5, kk = r & 31, kp = kp0 + kk;
-      df[(((long)(kp / CH) * 9 + tap) * Coutp + co0 + j) * CH + kp % CH] = from_float<T>(tile[j][kk * 9 + tap]);
+  for (int idx = threadIdx.x; idx < 9 * 32 * VPR; idx += 256) {
+    const int tap = idx / (32 * VPR), r = idx - tap * (32 * VPR);
+    float f[VEC];
+    {   // forward: K = input channels (kp), N = output channels; VEC consecutive kp of one output channel
+      const int j = r / VPR, kk = (r - j * VPR) * VEC, kp = kp0 + kk;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) f[e] = tile[j][(kk + e) * 9 + tap];
+      *(uint4*)(df + (((long)(kp / CH) * 9 + tap) * Coutp + co0 + j) * CH + kp % CH) = pack16<T>(f);
     }
-    if (dd) {   // data gradient: K = output channels, N = input channels, taps flipped
-      const int kk = r >> 5, j = r & 31, co = co0 + j;
-      dd[(((long)(co / CH) * 9 + tap) * Cinp + kp0 + kk) * CH + co % CH] = from_float<T>(tile[j][kk * 9 + (8 - tap)]);
+    if (dd) {   // data gradient: K = output channels, N = input channels, taps flipped; VEC consecutive co of one kp
+      const int kk = r / VPR, j = (r - kk * VPR) * VEC, co = co0 + j;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) f[e] = tile[j + e][kk * 9 + (8 - tap)];
+      *(uint4*)(dd + (((long)(co / CH) * 9 + tap) * Cinp + kp0 + kk) * CH + co % CH) = pack16<T>(f);
     }
   }
 }

@@ -345,19 +345,25 @@ def channel_sum(ptr, P, C, dtype, dev):
     return out
 
 
-_ZERO_GRADS = {}
+_ZERO_POOL = {}       # device -> [optimizer epoch, zero buffer, next free element]
 
 
 def _zero_grad_like(n, dev):
-    """Read-only all-zero fp32 vector, shared by every conv bias that sits ahead of a batch-statistics BatchNorm
-    (its gradient is identically zero): one allocation and one fill per (size, device) instead of one per layer
-    and step.  Nothing in the training path writes to a gradient other than scaling it, which keeps zeros zero."""
-    key = (n, str(dev))
-    t = _ZERO_GRADS.get(key)
-    if t is None:
-        t = torch.zeros(n, dtype=torch.float32, device=dev)
-        _ZERO_GRADS[key] = t
-    return t
+    """All-zero fp32 gradient for a conv bias that sits ahead of a batch-statistics BatchNorm (its gradient is
+    identically zero).  Slices of one zero buffer per device and optimizer step: ONE fill per step instead of a fill or
+    a copy per layer -- autograd adopts a fresh view as `.grad` without copying it (a tensor shared between parameters
+    would be cloned by AccumulateGrad: 18 small copies per U-Net step).  The slices are disjoint, and nothing in the
+    training path does more to a gradient than scale or reduce it, which keeps zeros zero."""
+    key = torch.device(dev)
+    if key.type == "cuda" and key.index is None:
+        key = torch.device("cuda", torch.cuda.current_device())
+    pool = _ZERO_POOL.get(key)
+    if pool is None or pool[0] != _OPT_EPOCH[0] or pool[2] + n > pool[1].numel():
+        pool = [_OPT_EPOCH[0], torch.zeros(max(16384, 4 * n), dtype=torch.float32, device=key), 0]
+        _ZERO_POOL[key] = pool
+    off = pool[2]
+    pool[2] = off + (n + 3) // 4 * 4          # keep every slice 16-byte aligned
+    return pool[1][off:off + n]
 
 
 _NBT_DEFER = None

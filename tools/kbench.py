@@ -104,7 +104,24 @@ def bn():
         print(f"bn_bwd C={C:5d}@{hw:3d}  {t:8.1f} us  {by/t/1e3:7.1f} GB/s (5 passes)")
 
 
+def pack():
+    """Weight re-layout after an optimizer step: one-pass forward + data-gradient pack against the two per-mode packs,
+    all 18 Conv3x3 weights of the U-Net."""
+    dt = torch.bfloat16
+    shapes = [(64, 3, 0), (64, 64, 0), (128, 64, 0), (128, 128, 0), (256, 128, 0), (256, 256, 0), (512, 256, 0), (512, 512, 0),
+              (1024, 512, 0), (1024, 1024, 0), (512, 512, 512), (512, 512, 0), (256, 256, 256), (256, 256, 0),
+              (128, 128, 128), (128, 128, 0), (64, 64, 64), (64, 64, 0)]
+    ws = [torch.randn((co, ca + cb, 3, 3), device="cuda") for co, ca, cb in shapes]
+    t_both = timeit(lambda: [ops.pack_conv_both(w, ca, cb, dt) for w, (co, ca, cb) in zip(ws, shapes)], 20)
+    t_two = timeit(lambda: [(ops.pack_conv(w, ca, cb, dt, 0), ops.pack_conv(w, ca, cb, dt, 1)) for w, (co, ca, cb) in zip(ws, shapes)], 20)
+    nbytes = sum(w.numel() for w in ws) * (4 + 2 + 2)
+    print(f"pack all 18 weights: one-pass {t_both:8.1f} us ({nbytes/t_both/1e3:7.1f} GB/s)   per-mode {t_two:8.1f} us")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pack":
+        pack()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bn":
         bn()
         sys.exit(0)
