@@ -125,13 +125,17 @@ def main():
     final_loss = loss.item()
 
     # ---- instrumented pass (rank 0): per-kernel-family HIP-event timings on the launch stream
+    # Every rank runs these steps (they contain the gradient all-reduce: a rank stepping alone would dead-lock the
+    # collective); only rank 0 records events.
     prof = {}
-    if rank == 0 and args.profile_steps > 0:
-        ops.TIMER = ops.KernelTimer()
+    if args.profile_steps > 0:
+        if rank == 0:
+            ops.TIMER = ops.KernelTimer()
         for _ in range(args.profile_steps):
             step()
-        prof = ops.TIMER.summary()
-        ops.TIMER = None
+        if rank == 0:
+            prof = ops.TIMER.summary()
+            ops.TIMER = None
     if world > 1:
         dist.barrier()
 
