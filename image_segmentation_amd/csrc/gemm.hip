@@ -50,6 +50,32 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
   const int nst = g.nchunks >> 1;          // stages per unit (>= 1)
   const int HW = g.H * g.W;
 
+  // the part of the epilogue all 512 threads run: 16-byte coalesced stores of the staged 256 x 128 tile
+  auto store_tile = [&](int uu) {
+    const long m0 = (long)(uu / NT) * G_BM;
+    const int n0 = (uu % NT) * G_BN;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 512;
+      const int m = idx >> 4, cc = idx & 15;
+      const long gm = m0 + m;
+      if (gm < M) {
+        const uint4 v = *(const uint4*)(smem + m * G_OP + cc * 16);
+        const int n = n0 + cc * 8;
+        bf16_t* dst;
+        if (MODE == 1) {   // pixel-shuffle store: channel n of the GEMM is (tap, co) of output pixel (2y + tap/2, 2x + tap%2)
+          const int tap = n / g.Cout, co = n - tap * g.Cout;
+          const long b = gm / HW;
+          const int r = (int)(gm - b * HW), y = r / g.W, x = r - y * g.W;
+          dst = (bf16_t*)g.out + ((((b * 2 * g.H + 2 * y + (tap >> 1)) * 2 * g.W) + 2 * x + (tap & 1)) * (long)g.Cout + co);
+        } else {
+          dst = (bf16_t*)g.out + gm * (long)N + n;
+        }
+        *(uint4*)dst = v;
+      }
+    }
+  };
+
   if (wave >= 4) {
     // =============================================== PRODUCERS ===============================================
     const int ptid = tid - 256;
@@ -118,31 +144,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
         __syncthreads();
       }
       __syncthreads();                                 // E1: consumers staged the output tile
-      // ---- all 512 threads store the tile (shared code below via goto-free duplication)
-      {
-        const long m0 = (long)(u / NT) * G_BM;
-        const int n0 = (u % NT) * G_BN;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int idx = tid + i * 512;
-          const int m = idx >> 4, cc = idx & 15;
-          const long gm = m0 + m;
-          if (gm < M) {
-            const uint4 v = *(const uint4*)(smem + m * G_OP + cc * 16);
-            const int n = n0 + cc * 8;
-            bf16_t* dst;
-            if (MODE == 1) {
-              const int tap = n / g.Cout, co = n - tap * g.Cout;
-              const long b = gm / HW;
-              const int r = (int)(gm - b * HW), y = r / g.W, x = r - y * g.W;
-              dst = (bf16_t*)g.out + ((((b * 2 * g.H + 2 * y + (tap >> 1)) * 2 * g.W) + 2 * x + (tap & 1)) * (long)g.Cout + co);
-            } else {
-              dst = (bf16_t*)g.out + gm * (long)N + n;
-            }
-            *(uint4*)dst = v;
-          }
-        }
-      }
+      store_tile(u);
       if (!has_next) break;
       __syncthreads();                                 // E2: tile consumed, the stage slots may be rewritten
       store(0);                                        // next unit's stage 0 (held in registers since the last steps)
@@ -225,30 +227,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
     }
     zero_acc();
     __syncthreads();                                   // E1
-    {
-      const long m0 = (long)(u / NT) * G_BM;
-      const int n0 = (u % NT) * G_BN;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = tid + i * 512;
-        const int m = idx >> 4, cc = idx & 15;
-        const long gm = m0 + m;
-        if (gm < M) {
-          const uint4 v = *(const uint4*)(smem + m * G_OP + cc * 16);
-          const int n = n0 + cc * 8;
-          bf16_t* dst;
-          if (MODE == 1) {
-            const int tap = n / g.Cout, co = n - tap * g.Cout;
-            const long b = gm / HW;
-            const int r = (int)(gm - b * HW), y = r / g.W, x = r - y * g.W;
-            dst = (bf16_t*)g.out + ((((b * 2 * g.H + 2 * y + (tap >> 1)) * 2 * g.W) + 2 * x + (tap & 1)) * (long)g.Cout + co);
-          } else {
-            dst = (bf16_t*)g.out + gm * (long)N + n;
-          }
-          *(uint4*)dst = v;
-        }
-      }
-    }
+    store_tile(u);
     if (!has_next) break;
     __syncthreads();                                   // E2
     u = un;
