@@ -32,6 +32,33 @@ MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}
 DC_BYTES_PER_IMAGE_BF16_256 = 593.7e6
 
 
+def _u01(n, seed):
+    """Portable deterministic uniform [0,1) stream of SURVEY.md 8c (splitmix64 finaliser, top 24 bits): the synthetic
+    inputs of the benchmark.  Restated here so that only the cpu_baseline leg touches oracle/."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) + np.uint64((seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return (z >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+
+def fill(shape, seed, lo, hi):
+    import numpy as np
+    import torch
+    n = int(np.prod(shape))
+    return torch.from_numpy((lo + (hi - lo) * _u01(n, seed)).astype(np.float32).reshape(shape))
+
+
+def labels(shape, seed, num_classes):
+    import numpy as np
+    import torch
+    n = int(np.prod(shape))
+    lab = np.clip(np.floor(num_classes * _u01(n, seed)), 0, num_classes - 1).astype(np.int64)
+    return torch.from_numpy(lab.reshape(shape))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,7 +83,6 @@ def main():
     import image_segmentation_amd as seg
     from image_segmentation_amd import ops
     from image_segmentation_amd.parallel import GradSync
-    from oracle.fill import fill, labels          # deterministic synthetic data (portable fill)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
