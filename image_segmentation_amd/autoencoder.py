@@ -52,7 +52,7 @@ class EncoderBlock(_DoubleConvBlock):
     def forward(self, x):
         y = self._double(x)
         dtype = self.compute_dtype or ops.get_compute_dtype()
-        pooled, skip = ops.MaxPoolSkipFn.apply(y, dtype)     # skip aliases y: its gradient is accumulated in the pool backward
+        pooled, skip = ops.MaxPoolSkipFn.apply(y, dtype, getattr(y, "_segk_bn2", None))     # skip aliases y: its gradient is accumulated in the pool backward
         return pooled, skip
 
 

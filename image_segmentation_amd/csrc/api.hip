@@ -14,6 +14,10 @@ int segk_bn_bwd_impl(const void*, const void*, void*, const float*, const float*
 int segk_channel_sum_impl(const void*, long, int, int, float*, float*, int, hipStream_t);
 int segk_maxpool_fwd_impl(const void*, void*, int, int, int, int, int, hipStream_t);
 int segk_maxpool_bwd_impl(const void*, const void*, void*, int, int, int, int, int, int, hipStream_t);
+int segk_maxpool_bwd_bnstat_impl(const void*, const void*, void*, int, int, int, int, int, const float*, const float*,
+                                 const float*, const float*, float*, int, hipStream_t);
+int segk_bn_bwd_from_part_impl(const void*, const void*, void*, const float*, const float*, const float*, const float*, long,
+                               int, int, const float*, int, float*, float*, float*, int, hipStream_t);
 int segk_nchw_to_nhwc_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
 int segk_nhwc_to_nchw_impl(const void*, float*, int, int, int, int, int, int, hipStream_t);
 int segk_pack_conv_weight_impl(const float*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -163,6 +167,17 @@ int segk_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int Cp, int
 int segk_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate, int dtype,
                         segk_stream_t s) {
   return segk_maxpool_bwd_impl(x, dy, dx, B, H, W, Cp, accumulate, dtype, (hipStream_t)s);
+}
+int segk_maxpool2x2_bwd_bnstat(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate,
+                               const float* scale, const float* shift, const float* mean, const float* rstd, float* part,
+                               int dtype, segk_stream_t s) {
+  return segk_maxpool_bwd_bnstat_impl(x, dy, dx, B, H, W, Cp, accumulate, scale, shift, mean, rstd, part, dtype, (hipStream_t)s);
+}
+int segk_bn_relu_bwd_from_part(const void* dy, const void* z, void* dz, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, long P, int Cp, int C, const float* part, int nb,
+                               float* dgamma, float* dbeta, float* coef, int dtype, segk_stream_t s) {
+  return segk_bn_bwd_from_part_impl(dy, z, dz, scale, shift, mean, rstd, P, Cp, C, part, nb, dgamma, dbeta, coef, dtype,
+                                    (hipStream_t)s);
 }
 int segk_head_fwd(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp, int C,
                   int ncls, int dtype, segk_stream_t s) {

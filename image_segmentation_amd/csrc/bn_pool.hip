@@ -266,15 +266,34 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   }
 }
 
-// dx (+)= route(dy) ; one thread per 2x2 window x channel vector (windows tile the even part of the image)
-template <typename T>
+// dx (+)= route(dy) ; one thread per 2x2 window x channel vector (windows tile the even part of the image).
+// STAT: x is the output y = relu(bn(z)) of a DoubleConv block and dx its complete gradient (skip gradient + routed
+// pool gradient): the kernel also accumulates that BatchNorm's backward reductions sum(g), sum(g * xhat) with
+// g = dx where y > 0 -- xhat is recovered from y itself where the ReLU is active, xhat = (y - shift) * rstd / scale - mean * rstd,
+// and pixels with y == 0 contribute nothing -- so the block's bn_bwd_reduce pass (a read of dx and z) disappears.
+// Needs a power-of-two number of channel vectors (a thread then keeps its channels) and scale != 0.
+template <typename T, bool STAT>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           T* __restrict__ dx, int B, int H, int W, int C,
-                                                          int accumulate) {
+                                                          int accumulate, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ part) {
   using E = ET<T>;
   const int Ho = H >> 1, Wo = W >> 1, CV = C / E::VEC;
   const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;  // also visit the odd border (gradient zero there)
   const long total = (long)B * Hc * Wc * CV;
+  float xa[E::VEC], xb[E::VEC], sg[E::VEC], sgx[E::VEC];
+  if (STAT) {
+    const int cv0 = threadIdx.x % CV;              // fixed for the thread: 256 and the grid stride are multiples of CV
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) {
+      const int c = cv0 * E::VEC + j;
+      const float sc = scale[c], rs = rstd[c];
+      xa[j] = sc != 0.f ? rs / sc : 0.f;
+      xb[j] = -shift[c] * xa[j] - mean[c] * rs;
+      sg[j] = 0.f; sgx[j] = 0.f;
+    }
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int cv = (int)(i % CV);
     long p = i / CV;
@@ -288,7 +307,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
-      if (inwin) unpack16<T>(*(const uint4*)(x + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC), v[k]);
+      if (inwin || (STAT && yy < H && xx < W))
+        unpack16<T>(*(const uint4*)(x + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC), v[k]);
     }
     int sel[E::VEC];
 #pragma unroll
@@ -312,8 +332,28 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
       for (int j = 0; j < E::VEC; ++j) {
         const float r = (inwin && sel[j] == k) ? g[j] : 0.f;
         o[j] = accumulate ? o[j] + r : r;
+        if (STAT) {
+          const float gg = v[k][j] > 0.f ? o[j] : 0.f;
+          sg[j] += gg;
+          sgx[j] = fmaf(gg, fmaf(v[k][j], xa[j], xb[j]), sgx[j]);
+        }
       }
       *(uint4*)dst = pack16<T>(o);
+    }
+  }
+  if (STAT) {
+    __shared__ float red[256][2 * E::VEC + 1];
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) { red[threadIdx.x][j] = sg[j]; red[threadIdx.x][E::VEC + j] = sgx[j]; }
+    __syncthreads();
+    for (int q = threadIdx.x; q < CV * E::VEC; q += 256) {
+      const int cv = q / E::VEC, j = q - cv * E::VEC;
+      float a = 0.f, bsum = 0.f;
+      for (int t = cv; t < 256; t += CV) {          // fixed order
+        a += red[t][j];
+        bsum += red[t][E::VEC + j];
+      }
+      ((float2*)part)[(size_t)blockIdx.x * C + q] = make_float2(a, bsum);
     }
   }
 }
@@ -445,6 +485,35 @@ static int bn_bwd_t(const void* dy, const void* z, void* dz, const float* scale,
   SEGK_CHECK_LAUNCH("bn_bwd_apply");
   return 0;
 }
+// finalize + apply from partials another kernel already produced (nb rows of [C][2])
+template <typename T>
+static int bn_bwd_from_part_t(const void* dy, const void* z, void* dz, const float* scale, const float* shift, const float* mean,
+                              const float* rstd, long P, int C, int C_real, const float* part, int nb, float* dgamma,
+                              float* dbeta, float* coef, hipStream_t st) {
+  using E = ET<T>;
+  int cvb, rows, gy;
+  lane_geometry(C, E::VEC, &cvb, &rows, &gy);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32), dim3(1024), 0, st, part, nb, C, C_real, (double)P, dgamma,
+                     dbeta, coef);
+  SEGK_CHECK_LAUNCH("bn_bwd_finalize");
+  long ga = (P + rows - 1) / rows;
+  if (ga > 4096) ga = 4096;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((int)ga, gy), dim3(256), 0, st, (const T*)dy, (const T*)z, (T*)dz,
+                     scale, shift, mean, rstd, coef, P, C, cvb, rows);
+  SEGK_CHECK_LAUNCH("bn_bwd_apply");
+  return 0;
+}
+int segk_bn_bwd_from_part_impl(const void* dy, const void* z, void* dz, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, long P, int C, int C_real, const float* part, int nb,
+                               float* dgamma, float* dbeta, float* coef, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(dy && z && dz && scale && shift && mean && rstd && part && dgamma && dbeta && coef && nb > 0,
+               "bn_bwd_from_part: bad arguments");
+  SEGK_REQUIRE(P > 0 && C > 0 && C % 32 == 0 && C_real > 0 && C_real <= C, "bn_bwd_from_part: bad shape");
+  return dtype == SEGK_DT_BF16
+             ? bn_bwd_from_part_t<bf16_t>(dy, z, dz, scale, shift, mean, rstd, P, C, C_real, part, nb, dgamma, dbeta, coef, st)
+             : bn_bwd_from_part_t<float>(dy, z, dz, scale, shift, mean, rstd, P, C, C_real, part, nb, dgamma, dbeta, coef, st);
+}
+
 int segk_bn_bwd_impl(const void* dy, const void* z, void* dz, const float* scale, const float* shift, const float* mean,
                      const float* rstd, long P, int C, int C_real, float* part, float* dgamma, float* dbeta, float* coef,
                      int dtype, hipStream_t st) {
@@ -478,12 +547,39 @@ int segk_maxpool_bwd_impl(const void* x, const void* dy, void* dx, int B, int H,
   long g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   if (dtype == SEGK_DT_BF16)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3((int)g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
-                       (bf16_t*)dx, B, H, W, C, accumulate);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, false>), dim3((int)g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       (bf16_t*)dx, B, H, W, C, accumulate, nullptr, nullptr, nullptr, nullptr, nullptr);
   else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((int)g), dim3(256), 0, st, (const float*)x, (const float*)dy,
-                       (float*)dx, B, H, W, C, accumulate);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<float, false>), dim3((int)g), dim3(256), 0, st, (const float*)x, (const float*)dy,
+                       (float*)dx, B, H, W, C, accumulate, nullptr, nullptr, nullptr, nullptr, nullptr);
   SEGK_CHECK_LAUNCH("maxpool_bwd");
+  return 0;
+}
+
+// blocks (= partial rows) of the fused pooling-backward + BatchNorm-reduce kernel, or 0 when the shape is not served
+int segk_maxpool_bwd_stat_blocks(int B, int H, int W, int C, int dtype) {
+  const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
+  if (B <= 0 || H < 2 || W < 2 || C <= 0 || C % 32 != 0) return 0;
+  const int cv = C / vec;
+  if ((cv & (cv - 1)) != 0 || cv > 256) return 0;
+  long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * cv;
+  long g = (total + 255) / 256;
+  return (int)(g > 1024 ? 1024 : g);
+}
+
+int segk_maxpool_bwd_bnstat_impl(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int accumulate,
+                                 const float* scale, const float* shift, const float* mean, const float* rstd, float* part,
+                                 int dtype, hipStream_t st) {
+  SEGK_REQUIRE(x && dy && dx && scale && shift && mean && rstd && part, "maxpool_bwd_bnstat: null pointer");
+  const int g = segk_maxpool_bwd_stat_blocks(B, H, W, C, dtype);
+  SEGK_REQUIRE(g > 0, "maxpool_bwd_bnstat: shape not served (channel vectors must be a power of two)");
+  if (dtype == SEGK_DT_BF16)
+    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, true>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       (bf16_t*)dx, B, H, W, C, accumulate, scale, shift, mean, rstd, part);
+  else
+    hipLaunchKernelGGL((maxpool_bwd_kernel<float, true>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)dy,
+                       (float*)dx, B, H, W, C, accumulate, scale, shift, mean, rstd, part);
+  SEGK_CHECK_LAUNCH("maxpool_bwd_bnstat");
   return 0;
 }
 

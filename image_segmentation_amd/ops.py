@@ -325,11 +325,21 @@ def bn_finalize(stats, tiles, C, count, conv_bias, bn_w, bn_b, rmean, rvar, mome
     return scale, shift, mean, rstd
 
 
-def bn_relu_bwd(dy_ptr, z_ptr, dz_ptr, scale, shift, mean, rstd, P, C, dtype, dev):
+def bn_relu_bwd(dy_ptr, z_ptr, dz_ptr, scale, shift, mean, rstd, P, C, dtype, dev, ready=None):
+    """ready = (partials, rows) when the kernel that wrote dy already accumulated the reductions
+    (segk_maxpool2x2_bwd_bnstat): only finalize + apply run."""
     Cp = pad32(C)
+    dgamma, dbeta = _f32(C, dev), _f32(C, dev)
+    if ready is not None:
+        part, nb = ready
+        coef = _f32(2 * Cp, dev)
+        with _span("bn_relu_bwd", 0.0, 3.0 * P * C * _es(dtype)):     # apply only: 2 reads + 1 write
+            _lib.call("segk_bn_relu_bwd_from_part", dy_ptr, z_ptr, dz_ptr, scale.data_ptr(), shift.data_ptr(),
+                      mean.data_ptr(), rstd.data_ptr(), P, Cp, C, part.data_ptr(), nb, dgamma.data_ptr(), dbeta.data_ptr(),
+                      coef.data_ptr(), _DT[dtype], _stream())
+        return dgamma, dbeta
     nb = _lib.query("segk_bn_bwd_blocks", P, Cp, _DT[dtype])
     part, coef = _f32(nb * Cp * 2, dev), _f32(2 * Cp, dev)
-    dgamma, dbeta = _f32(C, dev), _f32(C, dev)
     with _span("bn_relu_bwd", 0.0, 5.0 * P * C * _es(dtype)):     # reduce: 2 reads; apply: 2 reads + 1 write
         _lib.call("segk_bn_relu_bwd", dy_ptr, z_ptr, dz_ptr, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                   rstd.data_ptr(), P, Cp, C, part.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(),
@@ -474,6 +484,9 @@ class DoubleConvFn(torch.autograd.Function):
         ctx.training = training
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.save_for_backward(xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2, a1)
+        # the module hands these to a pooling layer behind it (MaxPoolSkipFn), whose backward then also accumulates this
+        # block's BN2 backward reductions while it writes the block's output gradient
+        mod._bn2_vectors = (sc2, sh2, mu2, rs2, dtype) if training else None
         return act_view(y, Cout)
 
     @staticmethod
@@ -492,7 +505,12 @@ class DoubleConvFn(torch.autograd.Function):
 
         # ---- second conv: BN2+ReLU backward, data gradient, weight gradient
         dz2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        dg2, dbe2 = bn_relu_bwd(pdy, z2.data_ptr(), dz2.data_ptr(), sc2, sh2, mu2, rs2, P, Cout, dtype, dev)
+        ready = getattr(dy, "_segk_bn_part", None)       # (partials, rows, key) from MaxPoolSkipFn.backward
+        if ready is not None and ready[2] == (sc2.data_ptr(), P, Coutp):
+            ready = ready[:2]
+        else:
+            ready = None
+        dg2, dbe2 = bn_relu_bwd(pdy, z2.data_ptr(), dz2.data_ptr(), sc2, sh2, mu2, rs2, P, Cout, dtype, dev, ready=ready)
         w2d = mod.cache.get(("w2d", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 1))
         da1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         conv3x3(dz2, dz2.data_ptr(), Coutp, 0, 0, w2d, da1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, alg=(Cout, Cout))
@@ -568,7 +586,9 @@ class MaxPoolSkipFn(torch.autograd.Function):
     instead of a pooling-backward pass plus a separate elementwise add over the full-resolution tensor."""
 
     @staticmethod
-    def forward(ctx, x, dtype):
+    def forward(ctx, x, dtype, bn=None):
+        """bn = (scale, shift, mean, rstd, dtype) of the BatchNorm that produced x = relu(bn(z)) in this compute dtype
+        (DoubleConvReLU._bn2_vectors), or None."""
         _require_cuda(x, "MaxPool2d")
         x_t, px, Cp = _raw(x, dtype)
         B, C, H, W = x.shape
@@ -577,6 +597,7 @@ class MaxPoolSkipFn(torch.autograd.Function):
             _lib.call("segk_maxpool2x2_fwd", px, y.data_ptr(), B, H, W, Cp, _DT[dtype], _stream())
         ctx.save_for_backward(x_t)
         ctx.dtype = dtype
+        ctx.bn = bn if (bn is not None and bn[4] == dtype and bn[0].numel() == Cp) else None
         return act_view(y, C), x_t.view_as(x_t)
 
     @staticmethod
@@ -586,7 +607,7 @@ class MaxPoolSkipFn(torch.autograd.Function):
         B, C, H, W = x_t.shape
         px, Cp = act_info(x_t, dtype)
         if dy is None:
-            return dskip, None
+            return dskip, None, None
         dy_t, pdy, _ = _raw(dy, dtype)
         if dskip is None:
             dx = act_view(torch.empty((B, H, W, Cp), dtype=dtype, device=x_t.device), C)
@@ -595,9 +616,20 @@ class MaxPoolSkipFn(torch.autograd.Function):
             # the skip gradient arrives as an act tensor (logical NCHW view of an NHWC buffer): add into its storage
             dx, pdx, _ = _raw(dskip, dtype)
             acc, nbytes = 1, 3.25
+        nb = _lib.query("segk_maxpool_bwd_stat_blocks", B, H, W, Cp, _DT[dtype]) if ctx.bn is not None else 0
+        if nb > 0:
+            # dx is the complete gradient of the producing block's output: accumulate its BN2 backward reductions on
+            # the way (the block's backward then skips its reduce pass over dx and z)
+            sc, sh, mu, rs, _ = ctx.bn
+            part = _f32(nb * Cp * 2, x_t.device)
+            with _span("maxpool_bwd", 0.0, nbytes * B * H * W * C * _es(dtype)):
+                _lib.call("segk_maxpool2x2_bwd_bnstat", px, pdy, pdx, B, H, W, Cp, acc, sc.data_ptr(), sh.data_ptr(),
+                          mu.data_ptr(), rs.data_ptr(), part.data_ptr(), _DT[dtype], _stream())
+            dx._segk_bn_part = (part, nb, (sc.data_ptr(), B * H * W, Cp))
+            return dx, None, None
         with _span("maxpool_bwd", 0.0, nbytes * B * H * W * C * _es(dtype)):
             _lib.call("segk_maxpool2x2_bwd", px, pdy, pdx, B, H, W, Cp, acc, _DT[dtype], _stream())
-        return dx, None
+        return dx, None, None
 
 
 class ConvT2x2Fn(torch.autograd.Function):

@@ -42,8 +42,10 @@ class DoubleConvReLU(_FusedBase):
     def forward(self, x, x_second=None):
         """x_second: optional second operand of a channel concat [x | x_second] (used by Up)."""
         s = self.doubleConvReLU
-        return ops.DoubleConvFn.apply(self, x, x_second, s[0].weight, s[0].bias, s[1].weight, s[1].bias,
-                                      s[3].weight, s[3].bias, s[4].weight, s[4].bias)
+        y = ops.DoubleConvFn.apply(self, x, x_second, s[0].weight, s[0].bias, s[1].weight, s[1].bias,
+                                   s[3].weight, s[3].bias, s[4].weight, s[4].bias)
+        y._segk_bn2 = self.__dict__.pop("_bn2_vectors", None)   # for a pooling layer behind this block (Down)
+        return y
 
 
 class Down(nn.Module):
@@ -60,7 +62,7 @@ class Down(nn.Module):
         dc = self.maxpool_doubleConv[1]
         dtype = dc.compute_dtype or ops.get_compute_dtype()
         if return_skip:
-            p, skip = ops.MaxPoolSkipFn.apply(x, dtype)
+            p, skip = ops.MaxPoolSkipFn.apply(x, dtype, getattr(x, "_segk_bn2", None))
             return dc(p), skip
         return dc(ops.MaxPoolFn.apply(x, dtype))
 

@@ -125,6 +125,19 @@ int segk_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int Cp, int
 int segk_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate,
                         int dtype, segk_stream_t s);
 
+/* Pooling backward of a DoubleConv block's output y = relu(bn(z)) (unet.py:40 behind :20-21) that ALSO accumulates that
+ * BatchNorm's backward reductions sum(g), sum(g*xhat) over the complete gradient it writes (xhat recovered from y where the
+ * ReLU is active): part holds segk_maxpool_bwd_stat_blocks() rows of [Cp][2] floats, finished by
+ * segk_bn_relu_bwd_from_part (finalize + apply, no reduce pass).  segk_maxpool_bwd_stat_blocks returns 0 when the shape
+ * is not served (Cp / vector width must be a power of two). */
+int segk_maxpool_bwd_stat_blocks(int B, int H, int W, int Cp, int dtype);
+int segk_maxpool2x2_bwd_bnstat(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate,
+                               const float* scale, const float* shift, const float* mean, const float* rstd, float* part,
+                               int dtype, segk_stream_t s);
+int segk_bn_relu_bwd_from_part(const void* dy, const void* z, void* dz, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, long P, int Cp, int C, const float* part, int nb,
+                               float* dgamma, float* dbeta, float* coef, int dtype, segk_stream_t s);
+
 /* ---- bilinear resize, align_corners=False (clip/clipunet.py:99-100: skip features 14x14 -> decoder grid) ----
  * x [B,IH,IW,Cp] -> y [B,OH,OW,Cp]; backward is a deterministic gather dy -> dx */
 int segk_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,

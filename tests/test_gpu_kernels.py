@@ -348,3 +348,45 @@ def test_pack_both_layouts_matches_single_packs(ops, dtype, case):
     f, d = ops.pack_conv_both(w, CA, CB, dtype)
     assert torch.equal(f, ops.pack_conv(w, CA, CB, dtype, 0))
     assert torch.equal(d, ops.pack_conv(w, CA, CB, dtype, 1))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 64, 16, 24, 1), (1, 128, 9, 14, 1), (2, 32, 8, 8, 0), (1, 1024, 4, 6, 1)])
+def test_maxpool_bwd_with_bn_reductions(ops, dtype, case):
+    """segk_maxpool2x2_bwd_bnstat: same dx as the plain pooling backward, and partials whose finalize + apply
+    (segk_bn_relu_bwd_from_part) reproduce the three-kernel BatchNorm backward on that dx."""
+    from image_segmentation_amd import _lib
+    B, C, H, W, acc = case
+    s = torch.cuda.current_stream().cuda_stream
+    z = fill((B, H, W, C), 1, -2, 2)
+    gamma, beta = fill((C,), 2, 0.5, 1.5), fill((C,), 3, -0.5, 0.5)
+    mu, var = z.reshape(-1, C).mean(0), z.reshape(-1, C).var(0, unbiased=False)
+    rs = 1.0 / torch.sqrt(var + 1e-5)
+    sc, sh = gamma * rs, beta - mu * gamma * rs
+    zq = z.to(dtype)
+    y = torch.relu(zq.float() * sc + sh).to(dtype)
+    dyp = fill((B, H // 2, W // 2, C), 4, -1, 1).to(dtype)
+    dskip = fill((B, H, W, C), 5, -1, 1).to(dtype)
+    dt = ops._DT[dtype]
+    yd, dypd, zd = dev(y), dev(dyp), dev(zq)
+    scd, shd, mud, rsd = dev(sc), dev(sh), dev(mu), dev(rs)
+    dx_ref = dev(dskip.clone()) if acc else torch.empty((B, H, W, C), dtype=dtype, device="cuda")
+    dx_new = dx_ref.clone()
+    _lib.call("segk_maxpool2x2_bwd", yd.data_ptr(), dypd.data_ptr(), dx_ref.data_ptr(), B, H, W, C, acc, dt, s)
+    nb = _lib.query("segk_maxpool_bwd_stat_blocks", B, H, W, C, dt)
+    assert nb > 0
+    part = torch.empty(nb * C * 2, device="cuda")
+    _lib.call("segk_maxpool2x2_bwd_bnstat", yd.data_ptr(), dypd.data_ptr(), dx_new.data_ptr(), B, H, W, C, acc, scd.data_ptr(),
+              shd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), part.data_ptr(), dt, s)
+    assert torch.equal(dx_new, dx_ref)
+    P = B * H * W
+    dz_a, dz_b = torch.empty_like(dx_ref), torch.empty_like(dx_ref)
+    dg_a, db_a = ops.bn_relu_bwd(dx_ref.data_ptr(), zd.data_ptr(), dz_a.data_ptr(), scd, shd, mud, rsd, P, C, dtype, "cuda")
+    dg_b, db_b = ops.bn_relu_bwd(dx_ref.data_ptr(), zd.data_ptr(), dz_b.data_ptr(), scd, shd, mud, rsd, P, C, dtype, "cuda",
+                                 ready=(part, nb))
+    t = 1e-4 if dtype == torch.float32 else 3e-2
+    scale = max(1.0, float(db_a.abs().max()), float(dg_a.abs().max()))
+    assert (back(db_a) - back(db_b)).abs().max() < t * scale
+    assert (back(dg_a) - back(dg_b)).abs().max() < t * scale
+    assert (back(dz_a) - back(dz_b)).abs().max() < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert _lib.query("segk_maxpool_bwd_stat_blocks", 1, 8, 8, 96, dt) == 0       # 12 or 24 channel vectors: not served
