@@ -57,6 +57,8 @@ SIGNATURES = {
     "segk_head_fwd": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_head_part_floats": (_i, [_l, _i]),
     "segk_head_bwd": (_i, [_fp, _vp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_head_bwd_blocks": (_i, [_l]),
+    "segk_head_bwd_bnstat": (_i, [_fp, _vp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _vp]),
     "segk_loss_part_floats": (_i, [_l]),
     "segk_loss_state_floats": (_i, []),
     "segk_loss_fwd": (_i, [_fp, _vp, _fp, _i, _i, _l, _i, _f, _f, _f, _fp, _fp, _vp]),

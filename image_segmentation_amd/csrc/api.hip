@@ -26,7 +26,8 @@ int segk_pack_conv3x3_both_impl(const float*, void*, void*, int, int, int, int, 
 int segk_wgrad_reduce_impl(const float*, int, float*, int, int, int, int, int, int, int, hipStream_t);
 int segk_head_fwd_impl(const void*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
 int segk_head_bwd_impl(const float*, const void*, const float*, void*, float*, float*, float*, int, int, int, int, int,
-                       int, int, hipStream_t);
+                       int, const float*, const float*, const float*, const float*, float*, int, hipStream_t);
+int segk_head_blocks_q(long);
 int segk_loss_fwd_impl(const float*, const long long*, const float*, int, int, long, int, float, float, float, float*,
                        float*, int, int, float, hipStream_t);
 int segk_loss_bwd_impl(const float*, const long long*, const float*, const float*, const float*, int, int, long, int,
@@ -185,7 +186,16 @@ int segk_head_fwd(const void* y, const float* w, const float* bias, float* logit
 }
 int segk_head_bwd(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
                   int B, int H, int W, int Cp, int C, int ncls, int dtype, segk_stream_t s) {
-  return segk_head_bwd_impl(dlogits, y, w, dy, part, dw, db, B, H, W, Cp, C, ncls, dtype, (hipStream_t)s);
+  return segk_head_bwd_impl(dlogits, y, w, dy, part, dw, db, B, H, W, Cp, C, ncls, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            dtype, (hipStream_t)s);
+}
+int segk_head_bwd_blocks(long P) { return segk_head_blocks_q(P); }
+int segk_head_bwd_bnstat(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
+                         int B, int H, int W, int Cp, int C, int ncls, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, float* bnpart, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(bnpart, "head_bwd_bnstat: null partials");
+  return segk_head_bwd_impl(dlogits, y, w, dy, part, dw, db, B, H, W, Cp, C, ncls, scale, shift, mean, rstd, bnpart, dtype,
+                            (hipStream_t)s);
 }
 int segk_loss_fwd(const float* logits, const int64_t* labels, const float* cw, int N, int C, long HW, int ignore_index,
                   float smooth, float dice_weight, float ce_weight, float* part, float* state, segk_stream_t s) {

@@ -76,10 +76,19 @@ template <typename T, int NC>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlog, const T* __restrict__ y,
                                                        const float* __restrict__ w, T* __restrict__ dy,
                                                        float* __restrict__ part, long P, long HW, int Cp, int C,
-                                                       int ncls, int cvb, int rows) {
+                                                       int ncls, int cvb, int rows, const float* __restrict__ bn_scale,
+                                                       const float* __restrict__ bn_shift, const float* __restrict__ bn_mean,
+                                                       const float* __restrict__ bn_rstd, float* __restrict__ bnpart) {
   using E = ET<T>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;                       // [rows][cvb][MAXC*VEC + MAXC]
+  // bnpart != NULL: y is the output relu(bn(z)) of the last DoubleConv block and dy its complete gradient: also accumulate
+  // that BatchNorm's backward reductions sum(g), sum(g*xhat) (xhat recovered from y where the ReLU is active), like
+  // maxpool_bwd_kernel<STAT> does for the Down blocks
+  const bool stat = bnpart != nullptr;
+  float xa[E::VEC], xb[E::VEC], sg[E::VEC], sgx[E::VEC];
+#pragma unroll
+  for (int j = 0; j < E::VEC; ++j) { xa[j] = 0.f; xb[j] = 0.f; sg[j] = 0.f; sgx[j] = 0.f; }
   constexpr int RW = MAXC * E::VEC + MAXC;
   const int cx = threadIdx.x % cvb, ry = threadIdx.x / cvb;
   const int cv = blockIdx.y * cvb + cx;
@@ -93,6 +102,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       const int c = cv * E::VEC + j;
       wr[k][j] = (active && k < ncls && c < C) ? w[(size_t)k * C + c] : 0.f;
       aw[k][j] = 0.f;
+    }
+  }
+  if (active && stat) {
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) {
+      const int c = cv * E::VEC + j;
+      const float sc = bn_scale[c], rs = bn_rstd[c];
+      xa[j] = sc != 0.f ? rs / sc : 0.f;
+      xb[j] = -bn_shift[c] * xa[j] - bn_mean[c] * rs;
     }
   }
   if (active) {
@@ -115,6 +133,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         }
       }
       *(uint4*)(dy + (size_t)p * Cp + cv * E::VEC) = pack16<T>(o);
+      if (stat) {
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) {
+          const float gg = f[j] > 0.f ? o[j] : 0.f;
+          sg[j] += gg;
+          sgx[j] = fmaf(gg, fmaf(f[j], xa[j], xb[j]), sgx[j]);
+        }
+      }
     }
   }
   if (ry < rows) {
@@ -142,6 +168,27 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         float s = 0.f;
         for (int r2 = 0; r2 < rows; ++r2) s += red[((size_t)r2 * cvb + cx) * RW + MAXC * E::VEC + k];
         dst[k * (Cp + 1) + Cp] = s;
+      }
+    }
+  }
+  if (stat) {
+    __syncthreads();
+    if (ry < rows) {
+      float* q = red + ((size_t)ry * cvb + cx) * RW;
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) { q[j] = sg[j]; q[E::VEC + j] = sgx[j]; }
+    }
+    __syncthreads();
+    if (ry == 0 && cv < Cp / E::VEC) {
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) {
+        float a = 0.f, b2 = 0.f;
+        for (int r2 = 0; r2 < rows; ++r2) {   // fixed order
+          const float* q = red + ((size_t)r2 * cvb + cx) * RW;
+          a += q[j];
+          b2 += q[E::VEC + j];
+        }
+        ((float2*)bnpart)[(size_t)blockIdx.x * Cp + cv * E::VEC + j] = make_float2(a, b2);
       }
     }
   }
@@ -409,7 +456,7 @@ int segk_head_fwd_impl(const void* y, const float* w, const float* bias, float* 
 
 template <typename T>
 static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
-                      long P, long HW, int Cp, int C, int ncls, hipStream_t st) {
+                      long P, long HW, int Cp, int C, int ncls, const float* const* bn, float* bnpart, hipStream_t st) {
   using E = ET<T>;
   const int cvec = Cp / E::VEC;
   const int cvb = cvec < 64 ? cvec : 64;
@@ -421,7 +468,8 @@ static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy
     constexpr int NC = decltype(NCc)::value;
     auto kern = head_bwd_kernel<T, NC>;
     if (!raise_lds((const void*)kern)) return false;
-    hipLaunchKernelGGL(kern, dim3(nb, gy), dim3(256), lds, st, dlog, (const T*)y, w, (T*)dy, part, P, HW, Cp, C, ncls, cvb, rows);
+    hipLaunchKernelGGL(kern, dim3(nb, gy), dim3(256), lds, st, dlog, (const T*)y, w, (T*)dy, part, P, HW, Cp, C, ncls, cvb, rows,
+                       bn ? bn[0] : nullptr, bn ? bn[1] : nullptr, bn ? bn[2] : nullptr, bn ? bn[3] : nullptr, bnpart);
     return true;
   };
   const bool ok = ncls <= 2 ? launch(std::integral_constant<int, 2>{})
@@ -436,13 +484,18 @@ static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy
 }
 
 int segk_head_bwd_impl(const float* dlog, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
-                       int B, int H, int W, int Cp, int C, int ncls, int dtype, hipStream_t st) {
+                       int B, int H, int W, int Cp, int C, int ncls, const float* bn_scale, const float* bn_shift,
+                       const float* bn_mean, const float* bn_rstd, float* bnpart, int dtype, hipStream_t st) {
   SEGK_REQUIRE(dlog && y && w && dy && part && dw && db && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
   SEGK_REQUIRE(ncls >= 1 && ncls <= MAXC && Cp % 32 == 0 && C > 0 && C <= Cp, "head_bwd: bad channels/classes");
+  SEGK_REQUIRE(!bnpart || (bn_scale && bn_shift && bn_mean && bn_rstd), "head_bwd: BatchNorm reductions need scale/shift/mean/rstd");
   const long P = (long)B * H * W, HW = (long)H * W;
-  return dtype == SEGK_DT_BF16 ? head_bwd_t<bf16_t>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, st)
-                               : head_bwd_t<float>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, st);
+  const float* bn[4] = {bn_scale, bn_shift, bn_mean, bn_rstd};
+  const float* const* bnp = bnpart ? bn : nullptr;
+  return dtype == SEGK_DT_BF16 ? head_bwd_t<bf16_t>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, bnp, bnpart, st)
+                               : head_bwd_t<float>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, bnp, bnpart, st);
 }
+int segk_head_blocks_q(long P) { return segk_head_blocks(P); }
 
 // ---- prompt model remix (prompt_based/prompt.py:33-56), 4 CLIP classes x 1 mask channel, fp32 NCHW ----
 //   p = softmax(clip_logits), m = sigmoid(mask_logit)

@@ -118,6 +118,7 @@ def _raw(t, dtype):
 # Optimizer steps invalidate every packed copy of a trainable parameter.  The autograd version counter alone is not
 # enough: fused optimizers (torch.optim.AdamW(fused=True), torch._fused_adamw_) update parameters in place WITHOUT
 # moving `param._version`, so a global post-step hook counts optimizer steps as well.
+FUSE_BN_REDUCE = True    # pooling / head backward also accumulate the producing block's BN2 backward reductions
 _OPT_EPOCH = [0]
 
 
@@ -616,7 +617,7 @@ class MaxPoolSkipFn(torch.autograd.Function):
             # the skip gradient arrives as an act tensor (logical NCHW view of an NHWC buffer): add into its storage
             dx, pdx, _ = _raw(dskip, dtype)
             acc, nbytes = 1, 3.25
-        nb = _lib.query("segk_maxpool_bwd_stat_blocks", B, H, W, Cp, _DT[dtype]) if ctx.bn is not None else 0
+        nb = _lib.query("segk_maxpool_bwd_stat_blocks", B, H, W, Cp, _DT[dtype]) if (ctx.bn is not None and FUSE_BN_REDUCE) else 0
         if nb > 0:
             # dx is the complete gradient of the producing block's output: accumulate its BN2 backward reductions on
             # the way (the block's backward then skips its reduce pass over dx and z)
@@ -835,6 +836,8 @@ class HeadFn(torch.autograd.Function):
                       ncls, _DT[dtype], _stream())
         ctx.dtype, ctx.dims = dtype, (B, C, H, W, ncls)
         ctx.save_for_backward(x_t, w)
+        bn = getattr(x, "_segk_bn2", None)        # the producing DoubleConv block's BN2 vectors (training mode)
+        ctx.bn = bn if (bn is not None and bn[4] == dtype and bn[0].numel() == Cp) else None
         return logits
 
     @staticmethod
@@ -852,10 +855,21 @@ class HeadFn(torch.autograd.Function):
         part = _f32(_lib.query("segk_head_part_floats", B * H * W, Cp), dev)
         dw = torch.empty(w.shape, dtype=torch.float32, device=dev)
         db = _f32(ncls, dev)
+        dyv = act_view(dy, C)
         with _span("head_bwd", 4.0 * B * H * W * C * ncls, B * H * W * (2 * C * _es(dtype) + 4 * ncls)):
-            _lib.call("segk_head_bwd", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(), dw.data_ptr(),
-                      db.data_ptr(), B, H, W, Cp, C, ncls, _DT[dtype], _stream())
-        return None, act_view(dy, C), dw, db
+            if ctx.bn is not None and FUSE_BN_REDUCE:
+                # dy is the complete gradient of the last block's output: accumulate its BN2 backward reductions here
+                sc, sh, mu, rs, _ = ctx.bn
+                nb = _lib.query("segk_head_bwd_blocks", B * H * W)
+                bnpart = _f32(nb * Cp * 2, dev)
+                _lib.call("segk_head_bwd_bnstat", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(),
+                          dw.data_ptr(), db.data_ptr(), B, H, W, Cp, C, ncls, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
+                          rs.data_ptr(), bnpart.data_ptr(), _DT[dtype], _stream())
+                dyv._segk_bn_part = (bnpart, nb, (sc.data_ptr(), B * H * W, Cp))
+            else:
+                _lib.call("segk_head_bwd", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(), dw.data_ptr(),
+                          db.data_ptr(), B, H, W, Cp, C, ncls, _DT[dtype], _stream())
+        return None, dyv, dw, db
 
 
 class SegLossFn(torch.autograd.Function):

@@ -190,6 +190,14 @@ int segk_head_part_floats(long P, int Cp);
 int segk_head_bwd(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
                   int B, int H, int W, int Cp, int C, int ncls, int dtype, segk_stream_t s);
 
+/* segk_head_bwd that also accumulates the BatchNorm backward reductions of the DoubleConv block whose output y the head
+ * reads (unet.py:103-105: up4 -> output): bnpart holds segk_head_bwd_blocks(P) rows of [Cp][2] floats for
+ * segk_bn_relu_bwd_from_part */
+int segk_head_bwd_blocks(long P);
+int segk_head_bwd_bnstat(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
+                         int B, int H, int W, int Cp, int C, int ncls, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, float* bnpart, int dtype, segk_stream_t s);
+
 /* ---- per-pixel CrossEntropy + soft Dice (training.py:47; utils/weighted_loss.py:31-98,140-166) ----
  * logits NCHW fp32 [N,C,HW], labels int64 [N,HW].  state (segk_loss_state_floats() floats):
  * [0]=dice_weight*dice+ce_weight*ce, [1]=ce, [2]=dice, rest = saved statistics for backward.

@@ -266,3 +266,24 @@ def test_fused_optimizer_steps_invalidate_packed_weights(seg, dtype):
     for (n, a), (_, b) in zip(m.named_parameters(), fresh.named_parameters()):
         assert torch.equal(a.grad, b.grad), n
     seg.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_reductions_fused_into_pool_and_head_backward(seg, dtype):
+    """The Down blocks' and the last block's BN2 backward reductions are accumulated by the pooling / head backward
+    kernels (xhat recovered from y): every parameter gradient must agree with the three-kernel BatchNorm backward."""
+    from image_segmentation_amd import ops
+    seg.set_compute_dtype(dtype)
+    X = fill((2, 3, 64, 48), 1, 0, 1).cuda(); Y = labels((2, 64, 48), 2, 3).cuda()
+    grads = []
+    for fused in (True, False):
+        ops.FUSE_BN_REDUCE = fused
+        m = seg.unet(3, 3); fill_module(m, 1000); m.cuda().train()
+        seg.CrossEntropyLoss()(m(X), Y).backward()
+        grads.append({n: p.grad.float().clone() for n, p in m.named_parameters()})
+    ops.FUSE_BN_REDUCE = True
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert (a - b).norm() <= tol * b.norm() + 1e-7, (n, (a - b).norm().item(), b.norm().item())
+    seg.set_compute_dtype(torch.bfloat16)
