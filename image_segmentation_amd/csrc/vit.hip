@@ -100,6 +100,26 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const T* __restrict__
   }
 }
 
+// 16-byte accesses: a lane owns float4 number lane + 64*i of the row (D % 4 == 0), LN4 = 8 float4 per lane covers D <= 2048
+constexpr int LN4 = LN_MAXPER / 4;
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&f)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&f)[4]) {
+  const float4 v = *(const float4*)p;
+  f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&f)[4]) {
+  const uint2 v = *(const uint2*)p;
+  f[0] = bf2f(v.x & 0xffffu); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = bf2f(v.y & 0xffffu); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&f)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&f)[4]) {
+  *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&f)[4]) {
+  *(uint2*)p = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ h, const T* __restrict__ delta,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -107,28 +127,50 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ 
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const int per = (D + 63) / 64;
-  float v[LN_MAXPER];
+  const int nq = D >> 2;                       // float4 per row
+  float v[LN4][4];
+  float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXPER; ++i) {
-    v[i] = 0.f;
-    const int c = lane + 64 * i;
-    if (i < per && c < D) {
-      float x = h[(size_t)row * D + c];
+  for (int i = 0; i < LN4; ++i) {
+    const int q = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+    if (q < nq) {
+      load4<float>(h + (size_t)row * D + q * 4, v[i]);
       if (delta) {
-        x += to_float<T>(delta[(size_t)row * Dp + c]);
-        h[(size_t)row * D + c] = x;
+        float d[4];
+        load4<T>(delta + (size_t)row * Dp + q * 4, d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] += d[e];
+        store4<float>(h + (size_t)row * D + q * 4, v[i]);
       }
-      v[i] = x;
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
   }
   if (!out) return;
-  float mean, rstd;
-  ln_rows(v, per, D, eps, mean, rstd);
+  const float mean = wave_sum(s) / (float)D;
+  float qs = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXPER; ++i) {
-    const int c = lane + 64 * i;
-    if (i < per && c < D) out[(size_t)row * Dp + c] = from_float<T>((v[i] - mean) * rstd * gamma[c] + beta[c]);
+  for (int i = 0; i < LN4; ++i)
+    if (lane + 64 * i < nq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        qs = fmaf(d, d, qs);
+      }
+    }
+  const float rstd = rsqrtf(wave_sum(qs) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < LN4; ++i) {
+    const int q = lane + 64 * i;
+    if (q < nq) {
+      float g[4], b[4], o[4];
+      load4<float>(gamma + q * 4, g);
+      load4<float>(beta + q * 4, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      store4<T>(out + (size_t)row * Dp + q * 4, o);
+    }
   }
 }
 
@@ -453,7 +495,8 @@ extern "C" int segk_add_layernorm(float* h, const void* delta, const float* gamm
                                   long M, int D, int Dp, int dtype, segk_stream_t s) {
   SEGK_REQUIRE(h && M > 0 && (delta || out), "add_layernorm: bad arguments");
   SEGK_REQUIRE(!out || (gamma && beta), "add_layernorm: LayerNorm output needs gamma and beta");
-  SEGK_REQUIRE(D > 0 && D <= 64 * LN_MAXPER && Dp >= D, "add_layernorm: hidden size %d unsupported (max %d)", D, 64 * LN_MAXPER);
+  SEGK_REQUIRE(D > 0 && D <= 64 * LN_MAXPER && Dp >= D && D % 4 == 0 && Dp % 4 == 0,
+               "add_layernorm: hidden size %d unsupported (multiple of 4, max %d)", D, 64 * LN_MAXPER);
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "add_layernorm: bad dtype");
   hipStream_t st = (hipStream_t)s;
   const int g = (int)((M + 3) / 4);
