@@ -236,7 +236,8 @@ def main():
         cpu = cpu_baseline(S)
 
     out = {
-        "metric": "images/sec (fwd+bwd) U-Net 3-class 256x256; IoU parity vs CPU ref",
+        "metric": "images/sec (fwd+bwd) U-Net 3-class 256x256; IoU parity vs CPU ref" if args.model == "unet" else
+                  "images/sec (frozen ViT-B/16 fwd + decoder fwd+bwd) CLIP-UNet 4-class 224x224 (BASELINE config 4, not the headline metric)",
         "value": round(img_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -506,8 +506,10 @@ class DoubleConvFn(torch.autograd.Function):
 
         # ---- second conv: BN2+ReLU backward, data gradient, weight gradient
         dz2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        ready = getattr(dy, "_segk_bn_part", None)       # (partials, rows, key) from MaxPoolSkipFn.backward
-        if ready is not None and ready[2] == (sc2.data_ptr(), P, Coutp):
+        # (partials, rows, key) from MaxPoolSkipFn / HeadFn backward; the key ties them to THIS BatchNorm and to the
+        # gradient tensor as it was when they were accumulated (an in-place add by autograd moves its version)
+        ready = getattr(dy, "_segk_bn_part", None)
+        if ready is not None and ready[2] == (sc2.data_ptr(), P, Coutp, dy._version):
             ready = ready[:2]
         else:
             ready = None
@@ -626,7 +628,7 @@ class MaxPoolSkipFn(torch.autograd.Function):
             with _span("maxpool_bwd", 0.0, nbytes * B * H * W * C * _es(dtype)):
                 _lib.call("segk_maxpool2x2_bwd_bnstat", px, pdy, pdx, B, H, W, Cp, acc, sc.data_ptr(), sh.data_ptr(),
                           mu.data_ptr(), rs.data_ptr(), part.data_ptr(), _DT[dtype], _stream())
-            dx._segk_bn_part = (part, nb, (sc.data_ptr(), B * H * W, Cp))
+            dx._segk_bn_part = (part, nb, (sc.data_ptr(), B * H * W, Cp, dx._version))
             return dx, None, None
         with _span("maxpool_bwd", 0.0, nbytes * B * H * W * C * _es(dtype)):
             _lib.call("segk_maxpool2x2_bwd", px, pdy, pdx, B, H, W, Cp, acc, _DT[dtype], _stream())
@@ -865,7 +867,7 @@ class HeadFn(torch.autograd.Function):
                 _lib.call("segk_head_bwd_bnstat", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(),
                           dw.data_ptr(), db.data_ptr(), B, H, W, Cp, C, ncls, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
                           rs.data_ptr(), bnpart.data_ptr(), _DT[dtype], _stream())
-                dyv._segk_bn_part = (bnpart, nb, (sc.data_ptr(), B * H * W, Cp))
+                dyv._segk_bn_part = (bnpart, nb, (sc.data_ptr(), B * H * W, Cp, dyv._version))
             else:
                 _lib.call("segk_head_bwd", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(), dw.data_ptr(),
                           db.data_ptr(), B, H, W, Cp, C, ncls, _DT[dtype], _stream())

@@ -287,3 +287,27 @@ def test_bn_reductions_fused_into_pool_and_head_backward(seg, dtype):
         a, b = grads[0][n], grads[1][n]
         assert (a - b).norm() <= tol * b.norm() + 1e-7, (n, (a - b).norm().item(), b.norm().item())
     seg.set_compute_dtype(torch.bfloat16)
+
+
+def test_fused_bn_reductions_survive_extra_consumers(seg):
+    """A block output that ALSO feeds a third consumer gets its gradient summed by autograd after the pooling backward
+    ran: the partial sums accumulated there are stale and must not be used (version / identity guard)."""
+    from image_segmentation_amd import ops
+    seg.set_compute_dtype(torch.float32)
+    x = fill((2, 3, 32, 32), 1, 0, 1).cuda()
+    grads = []
+    for fused in (True, False):
+        ops.FUSE_BN_REDUCE = fused
+        dc = seg.DoubleConvReLU(3, 64); down = seg.Down(64, 128)
+        fill_module(dc, 1000); fill_module(down, 2000)
+        dc.cuda().train(); down.cuda().train()
+        y = dc(x)
+        p, skip = down(y, return_skip=True)
+        loss = p.float().sum() * 0.3 + (skip.float() * fill(tuple(skip.shape), 7, -1, 1).cuda()).sum() + (y.float() ** 2).sum() * 0.1
+        loss.backward()
+        grads.append({n: q.grad.float().clone() for n, q in dc.named_parameters()})
+    ops.FUSE_BN_REDUCE = True
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert (a - b).norm() <= 2e-4 * b.norm() + 1e-6, (n, (a - b).norm().item(), b.norm().item())
+    seg.set_compute_dtype(torch.bfloat16)
