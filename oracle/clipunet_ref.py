@@ -5,8 +5,8 @@ Follows /root/reference/clip/clipunet.py:
                                      bilinear(skip -> x.size, align_corners=False);
                                      cat([x, skip]) (upsampled FIRST); Conv3x3(no bias)->BN->ReLU x2
   UNetDecoder   clipunet.py:108-144  init_conv 1x1 then blocks over reversed(skips)
-The ViT encoder (clipunet.py:7-65) is third-party (transformers.CLIPVisionModel) and stays
-stock; pretrained weights cannot be fetched offline, so pretrained parity is UNPINNED and the
+The ViT encoder (clipunet.py:7-65) is third-party (transformers.CLIPVisionModel): its restatement is
+oracle/clip_vit_ref.py; pretrained weights cannot be fetched offline, so pretrained parity is UNPINNED and the
 decoder is pinned with portable-fill features (SURVEY.md 8c answers C, D).
 """
 import torch
