@@ -50,6 +50,8 @@ SIGNATURES = {
     "segk_vit_patchify": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_vit_embed_ln": (_i, [_vp, _fp, _fp, _fp, _fp, _f, _fp, _i, _i, _i, _i, _i, _vp]),
     "segk_add_layernorm": (_i, [_fp, _vp, _fp, _fp, _f, _vp, _l, _i, _i, _i, _vp]),
+    "segk_linear_splitk": (_i, [_vp, _vp, _fp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "segk_add_layernorm_parts": (_i, [_fp, _vp, _i, _l, _fp, _fp, _f, _vp, _l, _i, _i, _i, _vp]),
     "segk_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "segk_vit_tokens_to_grid": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _vp]),
     "segk_resize_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

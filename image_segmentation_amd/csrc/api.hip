@@ -111,6 +111,20 @@ int segk_linear(const void* rows, const void* wpacked, const float* bias, void* 
   return segk_conv_igemm_launch(a, 1, dtype, (hipStream_t)s);
 }
 
+int segk_linear_splitk(const void* rows, const void* wpacked, const float* bias, void* out_parts, long M, int K, int N,
+                       int ksplit, int dtype, segk_stream_t s) {
+  // bf16 only: `ksplit` partial products [ksplit][M][N] (the consumer sums them: segk_add_layernorm_parts)
+  SEGK_REQUIRE(dtype == SEGK_DT_BF16, "linear_splitk: bf16 only");
+  SEGK_REQUIRE(M > 0 && M % 16 == 0 && K > 0 && K % 64 == 0 && N > 0 && ksplit >= 1, "linear_splitk: bad shape");
+  SEGK_REQUIRE(segk_gemm_pipe_ok(M, K / 32, K / 32, N, N, 0) && (K / 64) % ksplit == 0 && K / 64 / ksplit >= 1,
+               "linear_splitk: K=%d does not split %d ways into 64-element stages (or the shape is not served)", K, ksplit);
+  GemmArgs g{};
+  g.A = rows; g.w = (const char*)wpacked; g.bias = bias; g.out = out_parts;
+  g.M = M; g.N = N; g.nchunks = K / 32; g.nchA = K / 32; g.lda = K; g.H = 1; g.W = 1; g.Cout = N;
+  g.ksplit = ksplit; g.split_stride = M * (long)N;
+  return segk_gemm_pipe_launch(g, 0, (hipStream_t)s);
+}
+
 int segk_convt2x2_fwd(const void* in, const void* wpacked, const float* bias4, void* out, int B, int H, int W, int Cin,
                       int Cout, int dtype, segk_stream_t s) {
   // bias4: per-N bias of length 4*Cout (the layer bias repeated for the four taps) or NULL

@@ -41,19 +41,21 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
   const int N = g.N;
   const int NT = N / G_BN;
   const int MT = (int)((M + G_BM - 1) / G_BM);
-  const int U = MT * NT;
+  const int KS = g.ksplit > 1 ? g.ksplit : 1;   // split-K (plain mode): unit = (row tile, K split, channel tile)
+  const int U = MT * NT * KS;
   const int xcd = blockIdx.x & 7, upx = (U + 7) >> 3;
   const int GW = gridDim.x >> 3;
   int u = xcd * upx + (blockIdx.x >> 3);
   const int u_end = min(U, (xcd + 1) * upx);
   if (u >= u_end) return;
-  const int nst = g.nchunks >> 1;          // stages per unit (>= 1)
+  const int nst = (g.nchunks >> 1) / KS;   // stages per unit (>= 1)
   const int HW = g.H * g.W;
 
   // the part of the epilogue all 512 threads run: 16-byte coalesced stores of the staged 256 x 128 tile
   auto store_tile = [&](int uu) {
-    const long m0 = (long)(uu / NT) * G_BM;
+    const long m0 = (long)(uu / (NT * KS)) * G_BM;
     const int n0 = (uu % NT) * G_BN;
+    bf16_t* const obase = (bf16_t*)g.out + (size_t)((uu / NT) % KS) * g.split_stride;   // this split's partial output
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int idx = tid + i * 512;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
           const int r = (int)(gm - b * HW), y = r / g.W, x = r - y * g.W;
           dst = (bf16_t*)g.out + ((((b * 2 * g.H + 2 * y + (tap >> 1)) * 2 * g.W) + 2 * x + (tap & 1)) * (long)g.Cout + co);
         } else {
-          dst = (bf16_t*)g.out + gm * (long)N + n;
+          dst = obase + gm * (long)N + n;
         }
         *(uint4*)dst = v;
       }
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
     u32x4 ra[8], rb[4];
     long arow[8];                          // element offset of each of this thread's A rows (chunk 0, tap 0)
     auto unit_rows = [&](int uu) {
-      const long m0 = (long)(uu / NT) * G_BM;
+      const long m0 = (long)(uu / (NT * KS)) * G_BM;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         long m = m0 + prow + 32 * i;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
       }
     };
     auto load = [&](int uu, int s) {
-      const int kc = 2 * s + cch;
+      const int kc = 2 * (((uu / NT) % KS) * nst + s) + cch;
       long koff;
       if (MODE == 2) {
         const int tap = kc / g.nchA, cc = kc - tap * g.nchA;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
         const int n = (wn * 2 + nf) * 32 + lr;
-        const float bv = g.bias ? g.bias[n0 + n] : 0.f;
+        const float bv = (g.bias && (u / NT) % KS == 0) ? g.bias[n0 + n] : 0.f;   // split-K: the bias rides on split 0
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
           const int mb = (wm * 4 + mf) * 32 + 4 * lh;
@@ -255,7 +257,7 @@ int launch_mode(const GemmArgs& g, hipStream_t st) {
       SEGK_FAIL(-3, "gemm_pipe: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  const long U = ((g.M + G_BM - 1) / G_BM) * (g.N / G_BN);
+  const long U = ((g.M + G_BM - 1) / G_BM) * (g.N / G_BN) * (g.ksplit > 1 ? g.ksplit : 1);
   const int per_xcd = (int)((U + 7) / 8);
   int gw = g_num_cus() / 8;
   if (gw > per_xcd) gw = per_xcd;
@@ -295,6 +297,8 @@ int segk_gemm_pipe_launch(const GemmArgs& g, int mode, hipStream_t st) {
   SEGK_REQUIRE(g.A && g.w && g.out && g.M > 0, "gemm_pipe: null pointer / empty problem");
   SEGK_REQUIRE(segk_gemm_pipe_ok(g.M, g.nchunks, g.nchA, g.N, g.Cout, mode), "gemm_pipe: unsupported shape");
   SEGK_REQUIRE(g.M * 4 < 2147483647LL * 64, "gemm_pipe: row count too large");
+  SEGK_REQUIRE(g.ksplit <= 1 || (mode == 0 && !g.act && (g.nchunks >> 1) % g.ksplit == 0 && g.split_stride >= g.M * (long)g.N),
+               "gemm_pipe: split-K needs the plain mode, no activation and a K that splits into whole 64-element stages");
   if (mode == 1) return launch_mode<1>(g, st);
   if (mode == 2) return launch_mode<2>(g, st);
   return launch_mode<0>(g, st);

@@ -58,6 +58,8 @@ struct GemmArgs {
   int H, W;             // input grid of the ConvTranspose modes
   int Cout;             // pixel-shuffle store: channels per tap (N = 4*Cout)
   int act;              // 1 = quick_gelu on (acc + bias)
+  int ksplit;           // > 1: split-K, partial outputs [ksplit][M][N] (split_stride elements apart), bias on split 0
+  long split_stride;
 };
 int segk_gemm_pipe_ok(long M, int nchunks, int nchA, int N, int cout_shuffle, int mode);   // mode 0 plain, 1 shuffle, 2 un-shuffle
 int segk_gemm_pipe_launch(const GemmArgs& g, int mode, hipStream_t st);

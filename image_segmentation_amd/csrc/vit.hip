@@ -123,7 +123,8 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
 template <typename T>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ h, const T* __restrict__ delta,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float eps, T* __restrict__ out, long M, int D, int Dp) {
+                                                            float eps, T* __restrict__ out, long M, int D, int Dp,
+                                                            int nparts, long part_stride) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -138,10 +139,12 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ 
     if (q < nq) {
       load4<float>(h + (size_t)row * D + q * 4, v[i]);
       if (delta) {
-        float d[4];
-        load4<T>(delta + (size_t)row * Dp + q * 4, d);
+        for (int pp = 0; pp < nparts; ++pp) {   // split-K partial products of the GEMM before, fixed order
+          float d[4];
+          load4<T>(delta + (size_t)pp * part_stride + (size_t)row * Dp + q * 4, d);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] += d[e];
+          for (int e = 0; e < 4; ++e) v[i][e] += d[e];
+        }
         store4<float>(h + (size_t)row * D + q * 4, v[i]);
       }
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -491,9 +494,18 @@ extern "C" int segk_vit_embed_ln(const void* proj, const float* cls, const float
   return 0;
 }
 
+extern "C" int segk_add_layernorm_parts(float* h, const void* delta, int nparts, long part_stride, const float* gamma,
+                                        const float* beta, float eps, void* out, long M, int D, int Dp, int dtype,
+                                        segk_stream_t s);
 extern "C" int segk_add_layernorm(float* h, const void* delta, const float* gamma, const float* beta, float eps, void* out,
                                   long M, int D, int Dp, int dtype, segk_stream_t s) {
+  return segk_add_layernorm_parts(h, delta, 1, 0, gamma, beta, eps, out, M, D, Dp, dtype, s);
+}
+extern "C" int segk_add_layernorm_parts(float* h, const void* delta, int nparts, long part_stride, const float* gamma,
+                                        const float* beta, float eps, void* out, long M, int D, int Dp, int dtype,
+                                        segk_stream_t s) {
   SEGK_REQUIRE(h && M > 0 && (delta || out), "add_layernorm: bad arguments");
+  SEGK_REQUIRE(nparts >= 1 && (nparts == 1 || part_stride >= M * (long)Dp), "add_layernorm: bad partial-product layout");
   SEGK_REQUIRE(!out || (gamma && beta), "add_layernorm: LayerNorm output needs gamma and beta");
   SEGK_REQUIRE(D > 0 && D <= 64 * LN_MAXPER && Dp >= D && D % 4 == 0 && Dp % 4 == 0,
                "add_layernorm: hidden size %d unsupported (multiple of 4, max %d)", D, 64 * LN_MAXPER);
@@ -502,10 +514,10 @@ extern "C" int segk_add_layernorm(float* h, const void* delta, const float* gamm
   const int g = (int)((M + 3) / 4);
   if (dtype == SEGK_DT_BF16)
     hipLaunchKernelGGL(add_layernorm_kernel<bf16_t>, dim3(g), dim3(256), 0, st, h, (const bf16_t*)delta, gamma, beta, eps,
-                       (bf16_t*)out, M, D, Dp);
+                       (bf16_t*)out, M, D, Dp, nparts, part_stride);
   else
     hipLaunchKernelGGL(add_layernorm_kernel<float>, dim3(g), dim3(256), 0, st, h, (const float*)delta, gamma, beta, eps,
-                       (float*)out, M, D, Dp);
+                       (float*)out, M, D, Dp, nparts, part_stride);
   SEGK_CHECK_LAUNCH("add_layernorm");
   return 0;
 }

@@ -13,7 +13,7 @@ rows past B*T are scratch and never read back.
 import torch
 
 from . import _lib, ops
-from .ops import _DT, _stream, pad32
+from .ops import _DT, _p, _stream, pad32
 
 
 def _vision(clip_vit):
@@ -90,9 +90,24 @@ def forward_features(clip_vit, plan, x, skip_indices, dtype):
     Mp, Np = (M + 15) // 16 * 16, (B * N + 15) // 16 * 16
     Kp = pad32(C * ps * ps)
 
+    # GEMMs with N = D are 78 output tiles at B = 16 (256 CUs): split their K three ways when it divides into whole
+    # 64-element stages; the residual add sums the partial products (bf16 path only)
+    def ksplit(K):
+        return 3 if (dtype == torch.bfloat16 and Mp >= 128 and D % 128 == 0 and K % 192 == 0 and K // 192 >= 4) else 1
+    S_out, S_fc2 = ksplit(D), ksplit(I)
     patches, proj, h, a, qkv, ctx, o, f = plan.workspace(
         (B, C, H, W), [((Np, Kp), 0), ((Np, D), 0), ((Mp, D), 1), ((Mp, D), 0), ((Mp, 3 * D), 0), ((Mp, D), 0),
-                       ((Mp, D), 0), ((Mp, I), 0)], dtype, dev)
+                       ((max(S_out, S_fc2) * Mp, D), 0), ((Mp, I), 0)], dtype, dev)
+
+    def linear_to_o(src, w, bias, K, S):
+        if S > 1:
+            _lib.call("segk_linear_splitk", src.data_ptr(), w.data_ptr(), bias.data_ptr(), o.data_ptr(), Mp, K, D, S, dt, s)
+        else:
+            _lib.call("segk_linear", src.data_ptr(), w.data_ptr(), bias.data_ptr(), o.data_ptr(), Mp, K, D, 0, dt, s)
+
+    def add_ln(S, gamma, beta):
+        _lib.call("segk_add_layernorm_parts", h.data_ptr(), o.data_ptr(), S, Mp * D, _p(gamma), _p(beta), eps,
+                  a.data_ptr() if gamma is not None else 0, M, D, D, dt, s)
     # patch embedding: im2col + GEMM (Conv2d(3, D, ps, stride ps, bias=False))
     _lib.call("segk_vit_patchify", xin.data_ptr(), patches.data_ptr(), B, C, H, W, ps, Kp, dt, s)
     wp = plan.linear("patch", emb.patch_embedding.weight, dtype)
@@ -121,22 +136,18 @@ def forward_features(clip_vit, plan, x, skip_indices, dtype):
         with ops._span("vit_attention", 4.0 * B * heads * T * T * hd, M * 4.0 * D * es):
             _lib.call("segk_attention", qkv.data_ptr(), ctx.data_ptr(), B, T, heads, hd, 3 * D, D, float(hd) ** -0.5, dt, s)
         with ops._span("vit_gemm", 2.0 * M * D * D, 0.0):
-            _lib.call("segk_linear", ctx.data_ptr(), plan.linear(("out", li), at.out_proj.weight, dtype).data_ptr(),
-                      _f32(at.out_proj.bias).data_ptr(), o.data_ptr(), Mp, D, D, 0, dt, s)
-        _lib.call("segk_add_layernorm", h.data_ptr(), o.data_ptr(), _f32(layer.layer_norm2.weight).data_ptr(),
-                  _f32(layer.layer_norm2.bias).data_ptr(), eps, a.data_ptr(), M, D, D, dt, s)
+            linear_to_o(ctx, plan.linear(("out", li), at.out_proj.weight, dtype), _f32(at.out_proj.bias), D, S_out)
+        add_ln(S_out, _f32(layer.layer_norm2.weight), _f32(layer.layer_norm2.bias))
         with ops._span("vit_gemm", 2.0 * M * D * I, 0.0):
             _lib.call("segk_linear", a.data_ptr(), plan.linear(("fc1", li), layer.mlp.fc1.weight, dtype).data_ptr(),
                       _f32(layer.mlp.fc1.bias).data_ptr(), f.data_ptr(), Mp, D, I, 1, dt, s)
         with ops._span("vit_gemm", 2.0 * M * D * I, 0.0):
-            _lib.call("segk_linear", f.data_ptr(), plan.linear(("fc2", li), layer.mlp.fc2.weight, dtype).data_ptr(),
-                      _f32(layer.mlp.fc2.bias).data_ptr(), o.data_ptr(), Mp, I, D, 0, dt, s)
+            linear_to_o(f, plan.linear(("fc2", li), layer.mlp.fc2.weight, dtype), _f32(layer.mlp.fc2.bias), I, S_fc2)
         if li + 1 < L:      # residual add fused with the next layer's layer_norm1
             nxt = layers[li + 1]
-            _lib.call("segk_add_layernorm", h.data_ptr(), o.data_ptr(), _f32(nxt.layer_norm1.weight).data_ptr(),
-                      _f32(nxt.layer_norm1.bias).data_ptr(), eps, a.data_ptr(), M, D, D, dt, s)
+            add_ln(S_fc2, _f32(nxt.layer_norm1.weight), _f32(nxt.layer_norm1.bias))
         else:               # last layer: add only (last_hidden_state is taken before post_layernorm)
-            _lib.call("segk_add_layernorm", h.data_ptr(), o.data_ptr(), 0, 0, eps, 0, M, D, D, dt, s)
+            add_ln(S_fc2, None, None)
         if li + 1 in want:
             states[li + 1] = grid()
     last = states[L] if L in states else grid()

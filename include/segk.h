@@ -164,6 +164,12 @@ int segk_vit_embed_ln(const void* proj, const float* cls, const float* pos, cons
  * NULL: add only) -- CLIPEncoderLayer's residual connections fused with the next layer_norm1/2 */
 int segk_add_layernorm(float* h, const void* delta, const float* gamma, const float* beta, float eps, void* out, long M,
                        int D, int Dp, int dtype, segk_stream_t s);
+/* split-K forms for GEMMs too small to fill 256 CUs (ViT out_proj / fc2 at B = 16: 78 output tiles): `ksplit` partial
+ * products out_parts[ksplit][M][N] (bf16, bias on split 0), summed in fixed order by the residual add that follows */
+int segk_linear_splitk(const void* rows, const void* wpacked, const float* bias, void* out_parts, long M, int K, int N,
+                       int ksplit, int dtype, segk_stream_t s);
+int segk_add_layernorm_parts(float* h, const void* delta, int nparts, long part_stride, const float* gamma,
+                             const float* beta, float eps, void* out, long M, int D, int Dp, int dtype, segk_stream_t s);
 /* CLIPAttention: qkv [B*T][ldq] = [q | k | v] (heads*head_dim each) -> ctx [B*T][ldo] = softmax(q k^T * scale) v per
  * head; head_dim 32 or 64; the head's K and V must fit the 160 KiB LDS (T <= 320 fp32 / 640 bf16 at head_dim 64) */
 int segk_attention(const void* qkv, void* ctx, int B, int T, int heads, int head_dim, int ldq, int ldo, float scale,

@@ -178,3 +178,34 @@ def test_unfrozen_encoder_uses_stock_autograd(seg):
     bott, skips = enc(fill((1, 3, 80, 80), 9, -1, 1).cuda())
     assert bott.requires_grad and len(skips) == 2
     seg.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,K,N,S", [(3152, 768, 768, 3), (3152, 3072, 768, 3), (400, 384, 128, 2), (256, 256, 256, 1)])
+def test_linear_splitk_and_partial_sum_layernorm(seg, M, K, N, S):
+    """Split-K GEMM (bf16): the partial products sum to the full product (bias once), and the residual add + LayerNorm
+    that consumes them sums the parts in a fixed order."""
+    from image_segmentation_amd import _lib, ops
+    dtype = torch.bfloat16
+    x = fill((M, K), 1, -1, 1).to(dtype).float()
+    w = (fill((N, K), 2, -1, 1) / K ** 0.5).to(dtype).float()
+    b = fill((N,), 3, -0.5, 0.5)
+    ref = x.double() @ w.double().t() + b.double()
+    xd = x.cuda().to(dtype).contiguous()
+    wp = ops.pack_conv(w.cuda().reshape(N, K, 1, 1).contiguous(), K, 0, dtype, 0, taps=1)
+    bd = b.cuda()
+    parts = torch.zeros((S, M, N), dtype=dtype, device="cuda")
+    _lib.call("segk_linear_splitk", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), parts.data_ptr(), M, K, N, S, ops._DT[dtype], _stream())
+    got = parts.float().sum(0).cpu()
+    assert (got - ref.float()).abs().max() < 3e-2 * max(1.0, float(ref.abs().max()))
+    if N <= 2048:
+        h0 = fill((M, N), 4, -2, 2)
+        g, be = fill((N,), 5, 0.5, 1.5), fill((N,), 6, -0.5, 0.5)
+        h = h0.cuda().clone(); gd, bed = g.cuda(), be.cuda()
+        out = torch.empty((M, N), dtype=dtype, device="cuda")
+        _lib.call("segk_add_layernorm_parts", h.data_ptr(), parts.data_ptr(), S, M * N, gd.data_ptr(), bed.data_ptr(), 1e-5,
+                  out.data_ptr(), M, N, N, ops._DT[dtype], _stream())
+        hr = h0 + parts.float().sum(0).cpu()
+        assert (h.cpu() - hr).abs().max() < 1e-5
+        assert (out.float().cpu() - F.layer_norm(hr, (N,), g, be, 1e-5)).abs().max() < 3e-2
+    with pytest.raises(RuntimeError, match="split"):
+        _lib.call("segk_linear_splitk", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), parts.data_ptr(), M, K, N, 5, ops._DT[dtype], _stream())
