@@ -33,7 +33,15 @@ def pad32(c):
     return (c + 31) // 32 * 32
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """Handle of the current HIP stream of the current device.  The raw C entry points cost ~0.3 us; the
+    torch.cuda.current_stream() object path costs ~4 us, 270 times per training step."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 

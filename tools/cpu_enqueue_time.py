@@ -16,4 +16,13 @@ for _ in range(30): step()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"enqueue {1e3*(t1-t0)/30:.2f} ms/step, total {1e3*(t2-t0)/30:.2f} ms/step")
+print(f"30 steps: enqueue {1e3*(t1-t0)/30:.2f} ms/step, total {1e3*(t2-t0)/30:.2f} ms/step")
+# a short burst from an idle queue: no back-pressure from the launch queue
+best = 1e9
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): step()
+    best = min(best, (time.perf_counter() - t0) / 3)
+    torch.cuda.synchronize()
+print(f"3-step bursts from an idle queue: enqueue {1e3*best:.2f} ms/step")
