@@ -12,7 +12,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
   roofline     : the dominant kernel family of the step, timed live with HIP events on the launch stream in
                  a separate instrumented pass (the timed region itself carries no instrumentation);
   cpu_baseline : the CPU oracle (oracle/, stock PyTorch fp32 ops = the reference algorithm) timed on the host
-                 cores on a bounded sample of the same workload (rank 0, N=1 only);
+                 cores on a bounded sample of the same workload (rank 0, N=1 only); its `parity` entry is the
+                 metric's "IoU parity vs CPU ref": fp32-mode logits / argmax masks / mIoU of the HIP path against
+                 that same oracle on the same sample;
   kernels      : per-kernel-family ms/step and achieved TFLOP/s / GB/s (algorithmic counts).
 """
 import argparse
@@ -277,9 +279,35 @@ def cpu_baseline(S):
     for _ in range(k):
         step()
     dt = time.perf_counter() - t0
-    return {"value": round(Bc * k / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle unet(3,3) fp32 train step (fwd+CE+bwd+AdamW), B={Bc} of 32 images 3x{S}x{S}, "
-                      f"1 warm-up + {k} timed steps, torch CPU {threads} threads"}
+    out = {"value": round(Bc * k / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+           "sample": f"oracle unet(3,3) fp32 train step (fwd+CE+bwd+AdamW), B={Bc} of 32 images 3x{S}x{S}, "
+                     f"1 warm-up + {k} timed steps, torch CPU {threads} threads"}
+    # The metric's second half ("IoU parity vs CPU ref"): the same oracle, here as the CHECKER of the product path
+    # (fp32 parity mode, the trained oracle weights, the same sample): logits, argmax masks and mIoU side by side.
+    try:
+        import image_segmentation_amd as seg
+        from image_segmentation_amd.metrics import MetricsHistory
+        prev = seg.get_compute_dtype()
+        seg.set_compute_dtype(torch.float32)
+        hip = seg.unet(3, 3)
+        hip.load_state_dict(m.state_dict())
+        hip.cuda().train()
+        with torch.no_grad():
+            lr = m(X)
+            lh = hip(X.cuda())
+        seg.set_compute_dtype(prev)
+        a_cpu, a_hip = MetricsHistory(3), MetricsHistory(3)
+        for i in range(Bc):
+            a_cpu.accumulate(lr[i].cuda(), Y[i].cuda())
+            a_hip.accumulate(lh[i], Y[i].cuda())
+        _, iou_cpu, _ = a_cpu.compute_epoch_metrics()
+        _, iou_hip, _ = a_hip.compute_epoch_metrics()
+        out["parity"] = {"mode": "fp32 (exact-fp32 MFMA kernels)", "max_abs_logit_diff": float((lh.cpu() - lr).abs().max()),
+                         "argmax_masks_equal": bool(torch.equal(lh.argmax(1).cpu(), lr.argmax(1))),
+                         "miou_hip": iou_hip, "miou_cpu_ref": iou_cpu}
+    except Exception as e:          # the baseline number stands on its own; report why the check did not run
+        out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 if __name__ == "__main__":
