@@ -31,8 +31,10 @@ class _DoubleConvBlock(_FusedBase):
 
     def _double(self, xa, xb=None):
         c1, b1, c2, b2 = self._convs()
-        return ops.DoubleConvFn.apply(self, xa, xb, c1.weight, c1.bias, b1.weight, b1.bias, c2.weight, c2.bias, b2.weight,
-                                      b2.bias)
+        y = ops.DoubleConvFn.apply(self, xa, xb, c1.weight, c1.bias, b1.weight, b1.bias, c2.weight, c2.bias, b2.weight,
+                                   b2.bias)
+        y._segk_bn2 = self.__dict__.pop("_bn2_vectors", None)   # for a pooling layer / head behind this block
+        return y
 
 
 class EncoderBlock(_DoubleConvBlock):
