@@ -36,6 +36,7 @@ SIGNATURES = {
     "segk_wgrad_reduce": (_i, [_fp, _i, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_bn_finalize": (_i, [_fp, _i, _i, _i, _d, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _fp, _fp, _fp, _fp, _vp]),
     "segk_bn_relu_apply": (_i, [_vp, _vp, _fp, _fp, _l, _i, _i, _vp]),
+    "segk_bn_relu_apply_pool": (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "segk_bn_bwd_blocks": (_i, [_l, _i, _i]),
     "segk_bn_relu_bwd": (_i, [_vp, _vp, _vp, _fp, _fp, _fp, _fp, _l, _i, _i, _fp, _fp, _fp, _fp, _i, _vp]),
     "segk_channel_sum": (_i, [_vp, _l, _i, _i, _fp, _fp, _i, _vp]),

@@ -9,6 +9,7 @@ thread_local char g_segk_err[512] = "";
 int segk_bn_finalize_impl(const float*, int, int, int, double, const float*, const float*, const float*, float*, float*,
                           float, float, int, float*, float*, float*, float*, hipStream_t);
 int segk_bn_relu_apply_impl(const void*, void*, const float*, const float*, long, int, int, hipStream_t);
+int segk_bn_relu_apply_pool_impl(const void*, void*, void*, const float*, const float*, int, int, int, int, int, hipStream_t);
 int segk_bn_bwd_impl(const void*, const void*, void*, const float*, const float*, const float*, const float*, long, int,
                      int, float*, float*, float*, float*, int, hipStream_t);
 int segk_channel_sum_impl(const void*, long, int, int, float*, float*, int, hipStream_t);
@@ -166,6 +167,10 @@ int segk_bn_finalize(const float* stats, int tiles, int Cp, int C, double count,
 int segk_bn_relu_apply(const void* z, void* y, const float* scale, const float* shift, long P, int Cp, int dtype,
                        segk_stream_t s) {
   return segk_bn_relu_apply_impl(z, y, scale, shift, P, Cp, dtype, (hipStream_t)s);
+}
+int segk_bn_relu_apply_pool(const void* z, void* y, void* pooled, const float* scale, const float* shift, int B, int H, int W,
+                            int Cp, int dtype, segk_stream_t s) {
+  return segk_bn_relu_apply_pool_impl(z, y, pooled, scale, shift, B, H, W, Cp, dtype, (hipStream_t)s);
 }
 int segk_bn_relu_bwd(const void* dy, const void* z, void* dz, const float* scale, const float* shift, const float* mean,
                      const float* rstd, long P, int Cp, int C, float* part, float* dgamma, float* dbeta, float* coef,

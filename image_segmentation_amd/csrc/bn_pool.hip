@@ -241,6 +241,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// y = relu(z*scale + shift) AND its MaxPool2d(2,2) in one pass (a DoubleConv block whose output feeds a Down block):
+// one thread per 2x2 window x channel vector; the pooled value is the maximum of the ROUNDED y values, i.e. exactly what
+// maxpool_fwd_kernel reads back, so fused and unfused paths agree bit for bit.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __restrict__ z, T* __restrict__ y,
+                                                                 T* __restrict__ pooled, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, int B, int H, int W, int C) {
+  using E = ET<T>;
+  const int Ho = H >> 1, Wo = W >> 1, CV = C / E::VEC;
+  const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;   // also visit the odd border (no pooled output there)
+  const long total = (long)B * Hc * Wc * CV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int xo = (int)(p % Wc); p /= Wc;
+    const int yo = (int)(p % Hc);
+    const int b = (int)(p / Hc);
+    float sc[E::VEC], sh[E::VEC], mx[E::VEC];
+#pragma unroll
+    for (int j = 0; j < E::VEC; ++j) { sc[j] = scale[cv * E::VEC + j]; sh[j] = shift[cv * E::VEC + j]; mx[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
+      if (yy >= H || xx >= W) continue;
+      const size_t off = (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC;
+      float f[E::VEC];
+      unpack16<T>(*(const uint4*)(z + off), f);
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
+      const uint4 pk = pack16<T>(f);
+      *(uint4*)(y + off) = pk;
+      unpack16<T>(pk, f);                           // the rounded values the pooling would read back
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) mx[j] = fmaxf(mx[j], f[j]);   // y >= 0: 0 is a neutral start
+    }
+    if (yo < Ho && xo < Wo) *(uint4*)(pooled + (((size_t)(b * Ho + yo)) * Wo + xo) * C + cv * E::VEC) = pack16<T>(mx);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
@@ -452,6 +491,24 @@ int segk_bn_relu_apply_impl(const void* z, void* y, const float* scale, const fl
   SEGK_REQUIRE(z && y && scale && shift && P > 0 && C > 0 && C % 32 == 0, "bn_relu_apply: bad arguments");
   return dtype == SEGK_DT_BF16 ? bn_relu_apply_t<bf16_t>(z, y, scale, shift, P, C, st)
                                : bn_relu_apply_t<float>(z, y, scale, shift, P, C, st);
+}
+
+int segk_bn_relu_apply_pool_impl(const void* z, void* y, void* pooled, const float* scale, const float* shift, int B, int H,
+                                  int W, int C, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(z && y && pooled && scale && shift && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 32 == 0,
+               "bn_relu_apply_pool: bad arguments");
+  const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
+  long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec);
+  long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (dtype == SEGK_DT_BF16)
+    hipLaunchKernelGGL(bn_relu_apply_pool_kernel<bf16_t>, dim3((int)g), dim3(256), 0, st, (const bf16_t*)z, (bf16_t*)y,
+                       (bf16_t*)pooled, scale, shift, B, H, W, C);
+  else
+    hipLaunchKernelGGL(bn_relu_apply_pool_kernel<float>, dim3((int)g), dim3(256), 0, st, (const float*)z, (float*)y,
+                       (float*)pooled, scale, shift, B, H, W, C);
+  SEGK_CHECK_LAUNCH("bn_relu_apply_pool");
+  return 0;
 }
 
 int segk_bn_bwd_blocks(long P, int C, int dtype) {

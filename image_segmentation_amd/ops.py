@@ -485,9 +485,18 @@ class DoubleConvFn(torch.autograd.Function):
         if training:
             _bump_batch_counters(bn1, bn2)
         y = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        with _span("bn_relu_apply", 0.0, 2.0 * P * Cout * _es(dtype)):
-            _lib.call("segk_bn_relu_apply", z2.data_ptr(), y.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), P, Coutp,
-                      _DT[dtype], _stream())
+        pooled = None
+        if getattr(mod, "_emit_pool", False) and H >= 2 and W >= 2:
+            # this block's output feeds a Down block: BN+ReLU and its MaxPool2d(2,2) in one pass over z2
+            pooled = torch.empty((B, H // 2, W // 2, Coutp), dtype=dtype, device=dev)
+            with _span("bn_relu_apply", 0.0, 2.25 * P * Cout * _es(dtype)):
+                _lib.call("segk_bn_relu_apply_pool", z2.data_ptr(), y.data_ptr(), pooled.data_ptr(), sc2.data_ptr(),
+                          sh2.data_ptr(), B, H, W, Coutp, _DT[dtype], _stream())
+        else:
+            with _span("bn_relu_apply", 0.0, 2.0 * P * Cout * _es(dtype)):
+                _lib.call("segk_bn_relu_apply", z2.data_ptr(), y.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), P, Coutp,
+                          _DT[dtype], _stream())
+        mod._pooled_output = (pooled, dtype) if pooled is not None else None
 
         ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, CA, CB, Cout)
         ctx.training = training
@@ -603,9 +612,13 @@ class MaxPoolSkipFn(torch.autograd.Function):
         _require_cuda(x, "MaxPool2d")
         x_t, px, Cp = _raw(x, dtype)
         B, C, H, W = x.shape
-        y = torch.empty((B, H // 2, W // 2, Cp), dtype=dtype, device=x.device)
-        with _span("maxpool_fwd", 0.0, 1.25 * B * H * W * C * _es(dtype)):
-            _lib.call("segk_maxpool2x2_fwd", px, y.data_ptr(), B, H, W, Cp, _DT[dtype], _stream())
+        pre = getattr(x, "_segk_pooled", None)      # the producing block already pooled its output (same pass as BN+ReLU)
+        if pre is not None and pre[1] == dtype and tuple(pre[0].shape) == (B, H // 2, W // 2, Cp):
+            y = pre[0]
+        else:
+            y = torch.empty((B, H // 2, W // 2, Cp), dtype=dtype, device=x.device)
+            with _span("maxpool_fwd", 0.0, 1.25 * B * H * W * C * _es(dtype)):
+                _lib.call("segk_maxpool2x2_fwd", px, y.data_ptr(), B, H, W, Cp, _DT[dtype], _stream())
         ctx.save_for_backward(x_t)
         ctx.dtype = dtype
         ctx.bn = bn if (bn is not None and bn[4] == dtype and bn[0].numel() == Cp) else None

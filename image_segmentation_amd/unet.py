@@ -45,6 +45,7 @@ class DoubleConvReLU(_FusedBase):
         y = ops.DoubleConvFn.apply(self, x, x_second, s[0].weight, s[0].bias, s[1].weight, s[1].bias,
                                    s[3].weight, s[3].bias, s[4].weight, s[4].bias)
         y._segk_bn2 = self.__dict__.pop("_bn2_vectors", None)   # for a pooling layer behind this block (Down)
+        y._segk_pooled = self.__dict__.pop("_pooled_output", None)
         return y
 
 
@@ -98,6 +99,11 @@ class unet(_FusedBase):
         self.up4 = Up(self.scale * 128, self.scale * 64)
 
         self.output = nn.Conv2d(self.scale * 64, dout, kernel_size=1)
+        # the outputs of down1..down4 are pooled by the next Down block (forward below): those blocks emit the pooled
+        # tensor in the same pass as their final BN+ReLU
+        for blk in (self.down1, self.down2.maxpool_doubleConv[1], self.down3.maxpool_doubleConv[1],
+                    self.down4.maxpool_doubleConv[1]):
+            blk._emit_pool = True
 
     def set_compute_dtype(self, dtype):
         """Per-model override of ops.set_compute_dtype (torch.float32 parity mode / torch.bfloat16)."""

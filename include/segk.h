@@ -108,6 +108,10 @@ int segk_bn_finalize(const float* stats, int tiles, int Cp, int C, double count,
 /* y = relu(z*scale + shift) over P pixels */
 int segk_bn_relu_apply(const void* z, void* y, const float* scale, const float* shift, long P, int Cp, int dtype,
                        segk_stream_t s);
+/* ... and the MaxPool2d(2,2) of y in the same pass (unet.py:20-21 followed by :40 of the next Down block):
+ * pooled [B,H/2,W/2,Cp]; bit-identical to segk_bn_relu_apply + segk_maxpool2x2_fwd */
+int segk_bn_relu_apply_pool(const void* z, void* y, void* pooled, const float* scale, const float* shift, int B, int H, int W,
+                            int Cp, int dtype, segk_stream_t s);
 /* backward of y = relu(bn(z)): dz (may alias dy) and dgamma/dbeta.  part: segk_bn_bwd_blocks()*Cp*2 floats,
  * coef: 2*Cp floats of scratch. */
 int segk_bn_bwd_blocks(long P, int Cp, int dtype);

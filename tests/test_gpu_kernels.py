@@ -390,3 +390,20 @@ def test_maxpool_bwd_with_bn_reductions(ops, dtype, case):
     assert (back(dg_a) - back(dg_b)).abs().max() < t * scale
     assert (back(dz_a) - back(dz_b)).abs().max() < (1e-4 if dtype == torch.float32 else 2e-2)
     assert _lib.query("segk_maxpool_bwd_stat_blocks", 1, 8, 8, 96, dt) == 0       # 12 or 24 channel vectors: not served
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 64, 16, 24), (1, 96, 9, 14), (2, 32, 7, 5)])
+def test_bn_relu_apply_with_pool_is_bit_identical(ops, dtype, case):
+    from image_segmentation_amd import _lib
+    B, C, H, W = case
+    s = torch.cuda.current_stream().cuda_stream
+    z = dev(fill((B, H, W, C), 1, -2, 2).to(dtype))
+    sc, sh = dev(fill((C,), 2, 0.5, 1.5)), dev(fill((C,), 3, -0.5, 0.5))
+    dt = ops._DT[dtype]
+    y0 = torch.empty_like(z); p0 = torch.empty((B, H // 2, W // 2, C), dtype=dtype, device="cuda")
+    _lib.call("segk_bn_relu_apply", z.data_ptr(), y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), B * H * W, C, dt, s)
+    _lib.call("segk_maxpool2x2_fwd", y0.data_ptr(), p0.data_ptr(), B, H, W, C, dt, s)
+    y1 = torch.empty_like(z); p1 = torch.empty_like(p0)
+    _lib.call("segk_bn_relu_apply_pool", z.data_ptr(), y1.data_ptr(), p1.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, H, W, C, dt, s)
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
