@@ -17,6 +17,7 @@ _vp, _fp, _i, _l, _f, _d = C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float,
 # name -> (restype, argtypes); mirrors include/segk.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
     "segk_version": (_i, []),
+    "segk_build_id": (C.c_char_p, []),
     "segk_last_error": (C.c_char_p, []),
     "segk_nchw_to_nhwc": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_nhwc_to_nchw": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -100,6 +101,11 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.segk_last_error().decode()}")
+
+
+def build_id():
+    """Source hash compiled into the loaded library (see build.source_hash)."""
+    return load().segk_build_id().decode()
 
 
 def query(name, *args):

@@ -29,12 +29,10 @@ class _DoubleConvBlock(_FusedBase):
         c = self._convs()
         return c[1], c[3]
 
-    def _double(self, xa, xb=None):
+    def _double(self, xa, xb=None, emit_pool=False, head=None):
         c1, b1, c2, b2 = self._convs()
-        y = ops.DoubleConvFn.apply(self, xa, xb, c1.weight, c1.bias, b1.weight, b1.bias, c2.weight, c2.bias, b2.weight,
-                                   b2.bias)
-        y._segk_bn2 = self.__dict__.pop("_bn2_vectors", None)   # for a pooling layer / head behind this block
-        return y
+        params = (c1.weight, c1.bias, b1.weight, b1.bias, c2.weight, c2.bias, b2.weight, b2.bias)
+        return ops.double_conv(self, xa, xb, params, emit_pool=emit_pool, head=head)
 
 
 class EncoderBlock(_DoubleConvBlock):
@@ -52,9 +50,7 @@ class EncoderBlock(_DoubleConvBlock):
         return self.conv1, self.bn1, self.conv2, self.bn2
 
     def forward(self, x):
-        y = self._double(x)
-        dtype = self.compute_dtype or ops.get_compute_dtype()
-        pooled, skip = ops.MaxPoolSkipFn.apply(y, dtype, getattr(y, "_segk_bn2", None))     # skip aliases y: its gradient is accumulated in the pool backward
+        skip, pooled = self._double(x, emit_pool=True)     # BN+ReLU and the pooling in one pass, one autograd node
         return pooled, skip
 
 
@@ -88,7 +84,7 @@ class DecoderBlockWithSkips(_DoubleConvBlock):
         s = self.convs
         return s[0], s[1], s[3], s[4]
 
-    def forward(self, x, skip_features):
+    def forward(self, x, skip_features, head=None):
         x_upsampled = ops.ConvT2x2Fn.apply(self, x, self.up.weight, self.up.bias)
         if skip_features.shape[2:] != x_upsampled.shape[2:]:
             diffY = skip_features.size()[2] - x_upsampled.size()[2]
@@ -97,7 +93,7 @@ class DecoderBlockWithSkips(_DoubleConvBlock):
                 raise ValueError("Upsampled larger than skip")
             skip_features = skip_features[:, :, diffY // 2: diffY // 2 + x_upsampled.size()[2],
                                           diffX // 2: diffX // 2 + x_upsampled.size()[3]]
-        return self._double(x_upsampled, skip_features)     # concat [up | skip] never materialised
+        return self._double(x_upsampled, skip_features, head=head)     # concat [up | skip] never materialised
 
 
 class DecoderWithSkips(nn.Module):
@@ -107,10 +103,11 @@ class DecoderWithSkips(nn.Module):
         self.decoderBlock2 = DecoderBlockWithSkips(din_up=base_channels * 2, din_skip=base_channels * 2, dout=base_channels)
         self.decoderBlock3 = DecoderBlockWithSkips(din_up=base_channels, din_skip=base_channels, dout=base_channels)
 
-    def forward(self, bottleneck, skip3, skip2, skip1):
+    def forward(self, bottleneck, skip3, skip2, skip1, head=None):
+        """head: an nn.Conv2d(C, classes, 1) run inside the last block's autograd node (returns its logits)."""
         d1 = self.decoderBlock1(bottleneck, skip3)
         d2 = self.decoderBlock2(d1, skip2)
-        return self.decoderBlock3(d2, skip1)
+        return self.decoderBlock3(d2, skip1, head=head)
 
 
 class DecoderBlockNoSkips(_DoubleConvBlock):
@@ -231,5 +228,4 @@ class SegmentationAutoencoder(_FusedBase):
     def forward(self, x):
         with ops.defer_batch_counters():
             bottleneck, skip3, skip2, skip1 = self.encoder(x)
-            decoder_output = self.decoder(bottleneck, skip3, skip2, skip1)
-        return ops.HeadFn.apply(self, decoder_output, self.finalConv.weight, self.finalConv.bias)
+            return self.decoder(bottleneck, skip3, skip2, skip1, head=self.finalConv)

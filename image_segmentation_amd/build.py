@@ -21,6 +21,21 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def source_hash() -> str:
+    """sha256 over every file the library is built from (kernel sources, internal headers, the public header), in a
+    fixed order.  Compiled into the library (segk_build_id()), so a shipped libsegk.so can be checked against the
+    sources beside it (tests/test_abi.py) and profile records can name the build they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    paths = [os.path.join(CSRC, f) for f in files] + \
+            [os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "segk.h")]
+    for path in paths:
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
@@ -33,12 +48,16 @@ def _stale(obj, src):
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     objs, jobs = [], []
+    bid = source_hash()
+    stamp = os.path.join(CSRC, ".build_id")
+    id_changed = not os.path.exists(stamp) or open(stamp).read().strip() != bid
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, src):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+        extra = [f'-DSEGK_BUILD_ID="{bid}"'] if s == "api.hip" else []     # api.hip carries the id: rebuilt when it moves
+        if force or _stale(obj, src) or (extra and id_changed):
+            jobs.append([hipcc, *FLAGS, *extra, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -53,6 +72,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    with open(stamp, "w") as f:
+        f.write(bid + "\n")
     return LIB
 
 

@@ -102,7 +102,7 @@ class DecoderBlock(_FusedBase):
         self._dc.train(mode)
         return self
 
-    def forward(self, x, skip):
+    def forward(self, x, skip, head=None):
         dtype = self.compute_dtype or ops.get_compute_dtype()
         self._dc.compute_dtype = self.compute_dtype
         self._skip.compute_dtype = self.compute_dtype
@@ -110,7 +110,7 @@ class DecoderBlock(_FusedBase):
         skip = self._skip(skip)
         if skip.shape[2:] != x.shape[2:]:
             skip = ops.BilinearFn.apply(skip, x.shape[2:], dtype)
-        return self._dc(x, skip)                       # concat [x | skip] (upsampled FIRST, clipunet.py:102)
+        return self._dc(x, skip, head=head)            # concat [x | skip] (upsampled FIRST, clipunet.py:102)
 
 
 class UNetDecoder(_FusedBase):
@@ -125,11 +125,13 @@ class UNetDecoder(_FusedBase):
             self.decoder_blocks.append(DecoderBlock(in_channels, encoder_hidden_dim, out_ch))
             in_channels = out_ch
 
-    def forward(self, x, skips):
+    def forward(self, x, skips, head=None):
+        """head: an nn.Conv2d(C, classes, 1) run inside the last block's autograd node (returns its logits)."""
         self._init.compute_dtype = self.compute_dtype
         x = self._init(x)
-        for block, skip in zip(self.decoder_blocks, reversed(skips)):
-            x = block(x, skip)
+        last = len(self.decoder_blocks) - 1
+        for i, (block, skip) in enumerate(zip(self.decoder_blocks, reversed(skips))):
+            x = block(x, skip, head=head if i == last else None)
         return x
 
 
@@ -150,5 +152,4 @@ class ClipUNet(_FusedBase):
 
     def forward(self, x):
         x, skips = self.encoder(x)
-        decoder_output = self.decoder(x, skips)
-        return ops.HeadFn.apply(self, decoder_output, self.output_layer.weight, self.output_layer.bias)
+        return self.decoder(x, skips, head=self.output_layer)

@@ -40,7 +40,11 @@ static void fill_tiles(ConvArgs&) {}   // tile geometry is chosen per kernel con
 
 extern "C" {
 
-int segk_version(void) { return 100; }
+#ifndef SEGK_BUILD_ID
+#define SEGK_BUILD_ID "unknown"
+#endif
+int segk_version(void) { return 200; }
+const char* segk_build_id(void) { return SEGK_BUILD_ID; }
 const char* segk_last_error(void) { return g_segk_err; }
 
 int segk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cp, int dtype, segk_stream_t s) {

@@ -316,8 +316,36 @@ def wgrad(dz_ptr, CDp, ptrA, CAp, ptrB, CBp, B, H, W, geo, dtype, dev, scale=Non
     return slabs, S
 
 
-def wgrad_to_param(slabs, S, shape, N, CA, CB, taps, dev):
-    grad = torch.empty(shape, dtype=torch.float32, device=dev)
+_GRAD_DEST = None       # callback(param) -> fresh fp32 view to write the gradient into, or None (parallel.GradSync)
+_GRAD_DEST_USED = set()
+
+
+def grad_destination_begin(callback):
+    """Between begin and end, weight gradients are written straight into the buffer `callback(param)` returns (the
+    parameter's slice of its all-reduce bucket), each slice at most once (a weight used twice gets one slice and one
+    private buffer; autograd sums them)."""
+    global _GRAD_DEST
+    _GRAD_DEST = callback
+    _GRAD_DEST_USED.clear()
+
+
+def grad_destination_end():
+    global _GRAD_DEST
+    _GRAD_DEST = None
+    _GRAD_DEST_USED.clear()
+
+
+def _grad_buffer(param, shape, dev):
+    if _GRAD_DEST is not None and param is not None and param.data_ptr() not in _GRAD_DEST_USED:
+        d = _GRAD_DEST(param)
+        if d is not None and tuple(d.shape) == tuple(shape) and d.dtype == torch.float32:
+            _GRAD_DEST_USED.add(param.data_ptr())
+            return d
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def wgrad_to_param(slabs, S, shape, N, CA, CB, taps, dev, param=None):
+    grad = _grad_buffer(param, shape, dev)
     with _span("wgrad_reduce", 0.0, 4.0 * (S + 1) * grad.numel()):
         _lib.call("segk_wgrad_reduce", slabs.data_ptr(), S, grad.data_ptr(), N, CA, CB, pad32(N), pad32(CA),
                   pad32(CB) if CB else 0, taps, _stream())
@@ -423,23 +451,145 @@ def _param_f32(p):
 
 
 # ------------------------------------------------------------------------------------------------
-class DoubleConvFn(torch.autograd.Function):
-    """y = ReLU(BN2(Conv3x3(ReLU(BN1(Conv3x3([xa | xb]))))))  -- reference unet/unet.py:4-25 (bias=True) and
-    clip/clipunet.py:86-93 (bias=False).  xb is the optional second concat operand (unet.py:63 /
-    clipunet.py:102), consumed without materialising the concat.
+# Building blocks shared by the autograd Functions below.  Everything a backward kernel hands to a later backward
+# kernel (BatchNorm reductions accumulated by the pooling / head backward, channel sums of a concat gradient) stays
+# inside ONE autograd node's forward/backward pair: nothing is hung on tensors or modules.
+def _bn_momentum(bn):
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative moving average) is not supported by the fused "
+                                  "DoubleConv kernels; the reference uses the default momentum 0.1 (unet/unet.py:17,20)")
+    return bn.momentum
 
-    Forward kernels: conv3x3(+stats) -> bn_finalize -> conv3x3 with BN1+ReLU fused in its load prologue
-    (+stats) -> bn_finalize -> bn_relu_apply.  The conv biases never enter the kernels: ahead of a
-    training-mode BatchNorm they cancel (they only shift running_mean, handled in bn_finalize), and in
-    eval mode they fold into the BN shift.
+
+def _convt_fwd(mod, x_t, px, w, b, B, H, W, Cin, Cout, dtype, dev):
+    """ConvTranspose2d(k=2, s=2) forward as one GEMM with a pixel-shuffle store -> NHWC buffer [B,2H,2W,Coutp]."""
+    Cinp, Coutp = pad32(Cin), pad32(Cout)
+    wp = mod.cache.get(("tf", dtype), w, lambda: pack_convt(w, dtype, 0))
+
+    def bias4():
+        t = torch.zeros((4, Coutp), dtype=torch.float32, device=dev)
+        t[:, :Cout] = _param_f32(b)
+        return t
+    b4 = None if b is None else mod.cache.get(("tb", dtype), b, bias4)
+    out = torch.empty((B, 2 * H, 2 * W, Coutp), dtype=dtype, device=dev)
+    with _span("convt_fwd", 2.0 * B * H * W * Cin * 4 * Cout, B * H * W * (Cin + 4 * Cout) * _es(dtype)):
+        _lib.call("segk_convt2x2_fwd", px, wp.data_ptr(), _p(b4), out.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
+                  _stream())
+    return out
+
+
+def _convt_bwd(mod, x_t, w, pd, B, H, W, Cin, Cout, dtype, dev, need_dx, has_bias, chan_sum=None):
+    """Backward of _convt_fwd given the pointer of dout [B,2H,2W,Coutp] -> (dx act view or None, dw, db).
+    chan_sum: per-channel sum of dout when the kernel that wrote dout already produced it (the bias gradient)."""
+    Cinp, Coutp = pad32(Cin), pad32(Cout)
+    px = act_info(x_t, dtype)[0]
+    dx = None
+    if need_dx:
+        wd = mod.cache.get(("td", dtype), w, lambda: pack_convt(w, dtype, 1))
+        dxb = torch.empty((B, H, W, Cinp), dtype=dtype, device=dev)
+        with _span("convt_dgrad", 2.0 * B * H * W * Cin * 4 * Cout, B * H * W * (Cin + 4 * Cout) * _es(dtype)):
+            _lib.call("segk_convt2x2_dgrad", pd, wd.data_ptr(), dxb.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
+                      _stream())
+        dx = act_view(dxb, Cin)
+    slabs, S = wgrad(px, Cinp, pd, Coutp, 0, 0, B, H, W, 2, dtype, dev, alg=(Cin, Cout))
+    dw = wgrad_to_param(slabs, S, w.shape, Cin, Cout, 0, 4, dev, param=w)
+    db = None
+    if has_bias:
+        db = chan_sum if chan_sum is not None else channel_sum(pd, B * 4 * H * W, Cout, dtype, dev)
+    return dx, dw, db
+
+
+def _head_fwd(px, Cp, w, b, B, C, H, W, dtype, dev):
+    ncls = w.shape[0]
+    if ncls > _lib.MAX_CLASSES:
+        raise RuntimeError(f"output head supports up to {_lib.MAX_CLASSES} classes, got {ncls}")
+    w2 = _param_f32(w).reshape(ncls, C)
+    logits = torch.empty((B, ncls, H, W), dtype=torch.float32, device=dev)
+    with _span("head_fwd", 2.0 * B * H * W * C * ncls, B * H * W * (C * _es(dtype) + 4 * ncls)):
+        _lib.call("segk_head_fwd", px, w2.data_ptr(), _param_f32(b).data_ptr(), logits.data_ptr(), B, H, W, Cp, C,
+                  ncls, _DT[dtype], _stream())
+    return logits
+
+
+def _head_bwd(dlogits, px, Cp, w, B, C, H, W, dtype, dev, bn=None):
+    """-> (dy NHWC buffer, dw, db, bn_ready).  bn = (scale, shift, mean, rstd) of the BatchNorm whose output y the head
+    reads: the kernel then also accumulates that BatchNorm's backward reductions over the dy it writes
+    (bn_ready = (partials, rows) for bn_relu_bwd)."""
+    ncls = w.shape[0]
+    dl = dlogits
+    if dl.dtype != torch.float32 or not dl.is_contiguous():
+        dl = dl.float().contiguous()
+    w2 = _param_f32(w).reshape(ncls, C)
+    dy = torch.empty((B, H, W, Cp), dtype=dtype, device=dev)
+    part = _f32(_lib.query("segk_head_part_floats", B * H * W, Cp), dev)
+    dw = _grad_buffer(w, w.shape, dev)
+    db = _f32(ncls, dev)
+    ready = None
+    with _span("head_bwd", 4.0 * B * H * W * C * ncls, B * H * W * (2 * C * _es(dtype) + 4 * ncls)):
+        if bn is not None and FUSE_BN_REDUCE:
+            sc, sh, mu, rs = bn
+            nb = _lib.query("segk_head_bwd_blocks", B * H * W)
+            bnpart = _f32(nb * Cp * 2, dev)
+            _lib.call("segk_head_bwd_bnstat", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(),
+                      dw.data_ptr(), db.data_ptr(), B, H, W, Cp, C, ncls, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
+                      rs.data_ptr(), bnpart.data_ptr(), _DT[dtype], _stream())
+            ready = (bnpart, nb)
+        else:
+            _lib.call("segk_head_bwd", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(), dw.data_ptr(),
+                      db.data_ptr(), B, H, W, Cp, C, ncls, _DT[dtype], _stream())
+    return dy, dw, db, ready
+
+
+class BlockCfg:
+    """Static (non-tensor) configuration of one DoubleConvFn call."""
+    __slots__ = ("mod", "up_mod", "emit_pool")
+
+    def __init__(self, mod, up_mod=None, emit_pool=False):
+        self.mod, self.up_mod, self.emit_pool = mod, up_mod, emit_pool
+
+
+class DoubleConvFn(torch.autograd.Function):
+    """One autograd node per reference block:
+
+        [u = ConvTranspose2d(up_x)]                       reference unet/unet.py:59,62-63 (Up: xb = u, concat [xa | u])
+        y = ReLU(BN2(Conv3x3(ReLU(BN1(Conv3x3([xa | xb]))))))   unet/unet.py:4-25 (bias=True), clip/clipunet.py:86-93
+        [pooled = MaxPool2d(2,2)(y)]                      unet/unet.py:40 (the next Down block's pooling)
+        [logits = Conv2d(C, classes, 1)(y)]               unet/unet.py:91,105; clip/clipunet.py:181,187
+
+    xb is the optional second concat operand, consumed without materialising the concat.  The optional stages live in
+    the same node because their backward kernels feed each other: the pooling / head backward writes the complete
+    gradient of y and accumulates BN2's backward reductions on the way (the block's backward then skips its reduce pass
+    over dy and z2), and the concat data-gradient's per-channel sums are the ConvTranspose bias gradient.
+
+    Forward kernels: conv3x3(+stats) -> bn_finalize -> conv3x3 with BN1+ReLU fused in its load prologue (+stats) ->
+    bn_finalize -> bn_relu_apply (+pool).  The conv biases never enter the kernels: ahead of a training-mode BatchNorm
+    they cancel (they only shift running_mean, handled in bn_finalize), and in eval mode they fold into the BN shift.
+
+    Returns y, or (y, pooled) with cfg.emit_pool, or the fp32 NCHW logits when head_w is given.
     """
 
     @staticmethod
-    def forward(ctx, mod, xa, xb, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, cfg, xa, xb, w1, b1, g1, be1, w2, b2, g2, be2, up_x, up_w, up_b, head_w, head_b):
+        mod = cfg.mod
         dtype = mod.compute_dtype or _compute_dtype
         _require_cuda(xa, "DoubleConvReLU")
         dev = xa.device
         B, CA, H, W = xa.shape
+        # ---- optional ConvTranspose2d producing the second concat operand
+        up_t, up_dims = None, None
+        if up_x is not None:
+            if xb is not None:
+                raise ValueError("DoubleConvFn: give either xb or up_x")
+            _require_cuda(up_x, "ConvTranspose2d")
+            Bu, Cin_u, Hu, Wu = up_x.shape
+            Cout_u = up_w.shape[1]
+            if (2 * Hu, 2 * Wu) != (H, W):
+                raise RuntimeError(f"Sizes of tensors must match except in dimension 1: {tuple(xa.shape)} vs "
+                                   f"{(Bu, Cout_u, 2 * Hu, 2 * Wu)} (H and W must be multiples of 16)")
+            up_t, pux, _ = _raw(up_x, dtype)
+            ubuf = _convt_fwd(cfg.up_mod, up_t, pux, up_w, up_b, Bu, Hu, Wu, Cin_u, Cout_u, dtype, dev)
+            xb = act_view(ubuf, Cout_u)
+            up_dims = (Bu, Hu, Wu, Cin_u, Cout_u)
         CB = 0 if xb is None else xb.shape[1]
         Cout = w1.shape[0]
         Coutp = pad32(Cout)
@@ -447,7 +597,8 @@ class DoubleConvFn(torch.autograd.Function):
         bn1, bn2 = mod.bn_modules()
         xa_t, pA, CAp = _raw(xa, dtype)
         xb_t, pB, CBp = (None, 0, 0) if xb is None else _raw(xb, dtype)
-        if training and any(ctx.needs_input_grad):     # a backward will follow: both layouts in one pass per weight
+        want_grad = any(ctx.needs_input_grad)
+        if training and want_grad:     # a backward will follow: both layouts in one pass per weight
             w1p = mod.cache.get_pair(("w1f", dtype), ("w1d", dtype), w1, lambda: pack_conv_both(w1, CA, CB, dtype))
             w2p = mod.cache.get_pair(("w2f", dtype), ("w2d", dtype), w2, lambda: pack_conv_both(w2, Cout, 0, dtype))
         else:
@@ -460,17 +611,16 @@ class DoubleConvFn(torch.autograd.Function):
         z1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         st1 = _f32(_lib.query("segk_bn_stats_floats", tiles1, Coutp), dev) if training else None
         conv3x3(xa_t, pA, CAp, pB, CBp, w1p, z1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, stats=st1, alg=(CA + CB, Cout))
-        mom1 = bn1.momentum if bn1.momentum is not None else 0.1
         sc1, sh1, mu1, rs1 = bn_finalize(st1, tiles1, Cout, P, None if b1 is None else _param_f32(b1), _param_f32(g1),
-                                         _param_f32(be1), bn1.running_mean, bn1.running_var, mom1, bn1.eps, training,
-                                         dev)
+                                         _param_f32(be1), bn1.running_mean, bn1.running_var, _bn_momentum(bn1), bn1.eps,
+                                         training, dev)
         z2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         st2 = _f32(_lib.query("segk_bn_stats_floats", tiles2, Coutp), dev) if training else None
         # training: where the layer's kernel supports it, conv2's BN+ReLU prologue also writes the hidden activation
         # a1 = relu(bn1(z1)) it computes on the fly, so the weight-gradient pass reads a1 instead of re-deriving it
         # from z1 fragment by fragment (measured 25-30 % of that kernel)
         a1 = None
-        if training and any(ctx.needs_input_grad) and _lib.query("segk_conv_writes_act_q", Coutp, Coutp, _DT[dtype]):
+        if training and want_grad and _lib.query("segk_conv_writes_act_q", Coutp, Coutp, _DT[dtype]):
             a1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
             with _span("conv3x3_igemm", 2.0 * P * 9 * Cout * Cout, (P * 2 * Cout + 9.0 * Cout * Cout) * _es(dtype)):
                 _lib.call("segk_conv3x3_act", z1.data_ptr(), w2p.data_ptr(), sc1.data_ptr(), sh1.data_ptr(), z2.data_ptr(),
@@ -478,15 +628,16 @@ class DoubleConvFn(torch.autograd.Function):
         else:
             conv3x3(z1, z1.data_ptr(), Coutp, 0, 0, w2p, z2.data_ptr(), Coutp, 0, 0, B, H, W, dtype, scale=sc1,
                     shift=sh1, stats=st2, alg=(Cout, Cout))
-        mom2 = bn2.momentum if bn2.momentum is not None else 0.1
         sc2, sh2, mu2, rs2 = bn_finalize(st2, tiles2, Cout, P, None if b2 is None else _param_f32(b2), _param_f32(g2),
-                                         _param_f32(be2), bn2.running_mean, bn2.running_var, mom2, bn2.eps, training,
-                                         dev)
+                                         _param_f32(be2), bn2.running_mean, bn2.running_var, _bn_momentum(bn2), bn2.eps,
+                                         training, dev)
         if training:
             _bump_batch_counters(bn1, bn2)
         y = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         pooled = None
-        if getattr(mod, "_emit_pool", False) and H >= 2 and W >= 2:
+        if cfg.emit_pool:
+            if H < 2 or W < 2:
+                raise RuntimeError("MaxPool2d(2,2): input smaller than the window")
             # this block's output feeds a Down block: BN+ReLU and its MaxPool2d(2,2) in one pass over z2
             pooled = torch.empty((B, H // 2, W // 2, Coutp), dtype=dtype, device=dev)
             with _span("bn_relu_apply", 0.0, 2.25 * P * Cout * _es(dtype)):
@@ -496,41 +647,80 @@ class DoubleConvFn(torch.autograd.Function):
             with _span("bn_relu_apply", 0.0, 2.0 * P * Cout * _es(dtype)):
                 _lib.call("segk_bn_relu_apply", z2.data_ptr(), y.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), P, Coutp,
                           _DT[dtype], _stream())
-        mod._pooled_output = (pooled, dtype) if pooled is not None else None
+        logits = None
+        if head_w is not None:
+            logits = _head_fwd(y.data_ptr(), Coutp, head_w, head_b, B, Cout, H, W, dtype, dev)
 
-        ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, CA, CB, Cout)
+        ctx.cfg, ctx.dtype, ctx.dims = cfg, dtype, (B, H, W, CA, CB, Cout)
         ctx.training = training
         ctx.has_bias = (b1 is not None, b2 is not None)
-        ctx.save_for_backward(xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2, a1)
-        # the module hands these to a pooling layer behind it (MaxPoolSkipFn), whose backward then also accumulates this
-        # block's BN2 backward reductions while it writes the block's output gradient
-        mod._bn2_vectors = (sc2, sh2, mu2, rs2, dtype) if training else None
+        ctx.up_dims = up_dims
+        ctx.has_head = head_w is not None
+        ctx.save_for_backward(xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2, a1,
+                              y if (cfg.emit_pool or head_w is not None) else None, up_t, up_w, head_w)
+        if logits is not None:
+            return logits
+        if pooled is not None:
+            return act_view(y, Cout), act_view(pooled, Cout)
         return act_view(y, Cout)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *grads):
         if not ctx.training:
             raise NotImplementedError("DoubleConvReLU backward requires train() mode (batch-statistics BatchNorm)")
-        xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2, a1 = ctx.saved_tensors
-        mod, dtype = ctx.mod, ctx.dtype
+        (xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2, a1, y, up_t, up_w, head_w) = ctx.saved_tensors
+        cfg, dtype = ctx.cfg, ctx.dtype
+        mod = cfg.mod
         B, H, W, CA, CB, Cout = ctx.dims
         dev = z1.device
         Coutp, CAp, CBp = pad32(Cout), pad32(CA), (pad32(CB) if CB else 0)
         P = B * H * W
-        dy_t, pdy, _ = _raw(dy, dtype)
         pA = act_info(xa_t, dtype)[0]
         pB = 0 if xb_t is None else act_info(xb_t, dtype)[0]
+        need = ctx.needs_input_grad
+
+        # ---- gradient of the block output y, complete; `ready` = BN2's backward reductions when the kernel that wrote
+        # it accumulated them on the way
+        ready = None
+        d_head_w = d_head_b = None
+        keep = None
+        if ctx.has_head:
+            dy_buf, d_head_w, d_head_b, ready = _head_bwd(grads[0], y.data_ptr(), Coutp, head_w, B, Cout, H, W, dtype, dev,
+                                                          bn=(sc2, sh2, mu2, rs2))
+            pdy, keep = dy_buf.data_ptr(), dy_buf
+        elif cfg.emit_pool:
+            dy, dpool = grads
+            if dpool is None:
+                keep, pdy, _ = _raw(dy, dtype)
+            else:
+                dp_t, pdp, _ = _raw(dpool, dtype)
+                if dy is None:
+                    keep = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
+                    pdy, acc, nbytes = keep.data_ptr(), 0, 2.25
+                else:
+                    # the skip gradient arrives as an act tensor (fresh output of the consumer's data-gradient kernel;
+                    # converted copy otherwise): the pooled gradient is routed INTO its storage, one kernel instead of
+                    # a pooling backward plus a full-resolution add
+                    keep, pdy, _ = _raw(dy, dtype)
+                    acc, nbytes = 1, 3.25
+                nb = _lib.query("segk_maxpool_bwd_stat_blocks", B, H, W, Coutp, _DT[dtype]) if FUSE_BN_REDUCE else 0
+                with _span("maxpool_bwd", 0.0, nbytes * P * Cout * _es(dtype)):
+                    if nb > 0:
+                        part = _f32(nb * Coutp * 2, dev)
+                        _lib.call("segk_maxpool2x2_bwd_bnstat", y.data_ptr(), pdp, pdy, B, H, W, Coutp, acc,
+                                  sc2.data_ptr(), sh2.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), part.data_ptr(),
+                                  _DT[dtype], _stream())
+                        ready = (part, nb)
+                    else:
+                        _lib.call("segk_maxpool2x2_bwd", y.data_ptr(), pdp, pdy, B, H, W, Coutp, acc, _DT[dtype],
+                                  _stream())
+        else:
+            keep, pdy, _ = _raw(grads[0], dtype)
 
         # ---- second conv: BN2+ReLU backward, data gradient, weight gradient
         dz2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        # (partials, rows, key) from MaxPoolSkipFn / HeadFn backward; the key ties them to THIS BatchNorm and to the
-        # gradient tensor as it was when they were accumulated (an in-place add by autograd moves its version)
-        ready = getattr(dy, "_segk_bn_part", None)
-        if ready is not None and ready[2] == (sc2.data_ptr(), P, Coutp, dy._version):
-            ready = ready[:2]
-        else:
-            ready = None
         dg2, dbe2 = bn_relu_bwd(pdy, z2.data_ptr(), dz2.data_ptr(), sc2, sh2, mu2, rs2, P, Cout, dtype, dev, ready=ready)
+        del keep
         w2d = mod.cache.get(("w2d", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 1))
         da1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         conv3x3(dz2, dz2.data_ptr(), Coutp, 0, 0, w2d, da1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, alg=(Cout, Cout))
@@ -539,36 +729,59 @@ class DoubleConvFn(torch.autograd.Function):
         else:
             slabs, S = wgrad(dz2.data_ptr(), Coutp, z1.data_ptr(), Coutp, 0, 0, B, H, W, 0, dtype, dev, scale=sc1,
                              shift=sh1, alg=(Cout, Cout))
-        dw2 = wgrad_to_param(slabs, S, w2.shape, Cout, Cout, 0, 9, dev)
+        dw2 = wgrad_to_param(slabs, S, w2.shape, Cout, Cout, 0, 9, dev, param=w2)
         del slabs, dz2
 
         # ---- first conv (dz1 overwrites da1 in place: da1 is private to this function)
         dg1, dbe1 = bn_relu_bwd(da1.data_ptr(), z1.data_ptr(), da1.data_ptr(), sc1, sh1, mu1, rs1, P, Cout, dtype, dev)
         dz1 = da1
         dxa = dxb = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        dxb_buf, chan_sum = None, None
+        has_up = ctx.up_dims is not None
+        if need[1] or need[2] or has_up:
             w1d = mod.cache.get(("w1d", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 1))
             dxa_buf = torch.empty((B, H, W, CAp), dtype=dtype, device=dev)
             dxb_buf = torch.empty((B, H, W, CBp), dtype=dtype, device=dev) if CB else None
-            # with a concat operand (the ConvTranspose output of an Up block) the kernel's per-channel-sum epilogue
-            # also yields sum_pixels(dxb): exactly the bias gradient ConvT2x2Fn needs, without another pass over dxb
+            # with the ConvTranspose output as concat operand the kernel's per-channel-sum epilogue also yields
+            # sum_pixels(dxb): exactly the ConvTranspose bias gradient, without another pass over dxb
             std = None
-            if CB:
+            if has_up:
                 tiles_d = _lib.query("segk_conv_tiles", B, H, W, Coutp, CAp + CBp, _DT[dtype])
                 std = _f32(_lib.query("segk_bn_stats_floats", tiles_d, CAp + CBp), dev)
             conv3x3(dz1, dz1.data_ptr(), Coutp, 0, 0, w1d, dxa_buf.data_ptr(), CAp, _p(dxb_buf), CBp, B, H, W, dtype,
                     stats=std, alg=(Cout, CA + CB))
             dxa = act_view(dxa_buf, CA)
             dxb = act_view(dxb_buf, CB) if CB else None
-            if CB:
+            if has_up:
                 part = std[:tiles_d * (CAp + CBp) * 2].view(tiles_d, CAp + CBp, 2)
-                dxb._segk_channel_sum = part[:, CAp:CAp + CB, 0].sum(dim=0)
+                chan_sum = part[:, CAp:CAp + CB, 0].sum(dim=0)
         slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev, alg=(Cout, CA + CB))
-        dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev)
+        dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev, param=w1)
+        del slabs
         # conv biases ahead of a batch-statistics BatchNorm have an identically zero gradient
         db1 = _zero_grad_like(Cout, dev) if ctx.has_bias[0] else None
         db2 = _zero_grad_like(Cout, dev) if ctx.has_bias[1] else None
-        return None, dxa, dxb, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2
+
+        d_up_x = d_up_w = d_up_b = None
+        if has_up:
+            Bu, Hu, Wu, Cin_u, Cout_u = ctx.up_dims
+            d_up_x, d_up_w, d_up_b = _convt_bwd(cfg.up_mod, up_t, up_w, dxb_buf.data_ptr(), Bu, Hu, Wu, Cin_u, Cout_u, dtype,
+                                                dev, need[11], cfg.up_mod.upsample.bias is not None, chan_sum=chan_sum)
+            dxb = None                   # xb was internal
+        return (None, dxa, dxb, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, d_up_x, d_up_w, d_up_b, d_head_w, d_head_b)
+
+
+def double_conv(mod, xa, xb, params, emit_pool=False, head=None, up_mod=None, up_x=None):
+    """Module-side entry: params = (w1, b1, g1, be1, w2, b2, g2, be2); head = nn.Conv2d(C, classes, 1) or None;
+    up_mod = the module owning `upsample` (nn.ConvTranspose2d) whose output is the second concat operand."""
+    cfg = BlockCfg(mod, up_mod, emit_pool and head is None)
+    uw = ub = None
+    if up_mod is not None:
+        uw, ub = up_mod.upsample.weight, up_mod.upsample.bias
+    hw = hb = None
+    if head is not None:
+        hw, hb = head.weight, head.bias
+    return DoubleConvFn.apply(cfg, xa, xb, *params, up_x, uw, ub, hw, hb)
 
 
 class MaxPoolFn(torch.autograd.Function):
@@ -599,63 +812,6 @@ class MaxPoolFn(torch.autograd.Function):
         return act_view(dx, C), None
 
 
-class MaxPoolSkipFn(torch.autograd.Function):
-    """MaxPool2d(2,2) of a tensor that is ALSO consumed as a skip connection (unet.py:96-103: x1..x4 feed both the
-    next Down block and an Up block).  Returns (pooled, skip) where skip aliases the input; the backward then
-    receives both gradients and routes the pooled one INTO the skip gradient in one kernel (accumulate mode),
-    instead of a pooling-backward pass plus a separate elementwise add over the full-resolution tensor."""
-
-    @staticmethod
-    def forward(ctx, x, dtype, bn=None):
-        """bn = (scale, shift, mean, rstd, dtype) of the BatchNorm that produced x = relu(bn(z)) in this compute dtype
-        (DoubleConvReLU._bn2_vectors), or None."""
-        _require_cuda(x, "MaxPool2d")
-        x_t, px, Cp = _raw(x, dtype)
-        B, C, H, W = x.shape
-        pre = getattr(x, "_segk_pooled", None)      # the producing block already pooled its output (same pass as BN+ReLU)
-        if pre is not None and pre[1] == dtype and tuple(pre[0].shape) == (B, H // 2, W // 2, Cp):
-            y = pre[0]
-        else:
-            y = torch.empty((B, H // 2, W // 2, Cp), dtype=dtype, device=x.device)
-            with _span("maxpool_fwd", 0.0, 1.25 * B * H * W * C * _es(dtype)):
-                _lib.call("segk_maxpool2x2_fwd", px, y.data_ptr(), B, H, W, Cp, _DT[dtype], _stream())
-        ctx.save_for_backward(x_t)
-        ctx.dtype = dtype
-        ctx.bn = bn if (bn is not None and bn[4] == dtype and bn[0].numel() == Cp) else None
-        return act_view(y, C), x_t.view_as(x_t)
-
-    @staticmethod
-    def backward(ctx, dy, dskip):
-        (x_t,) = ctx.saved_tensors
-        dtype = ctx.dtype
-        B, C, H, W = x_t.shape
-        px, Cp = act_info(x_t, dtype)
-        if dy is None:
-            return dskip, None, None
-        dy_t, pdy, _ = _raw(dy, dtype)
-        if dskip is None:
-            dx = act_view(torch.empty((B, H, W, Cp), dtype=dtype, device=x_t.device), C)
-            pdx, acc, nbytes = dx.data_ptr(), 0, 2.25
-        else:
-            # the skip gradient arrives as an act tensor (logical NCHW view of an NHWC buffer): add into its storage
-            dx, pdx, _ = _raw(dskip, dtype)
-            acc, nbytes = 1, 3.25
-        nb = _lib.query("segk_maxpool_bwd_stat_blocks", B, H, W, Cp, _DT[dtype]) if (ctx.bn is not None and FUSE_BN_REDUCE) else 0
-        if nb > 0:
-            # dx is the complete gradient of the producing block's output: accumulate its BN2 backward reductions on
-            # the way (the block's backward then skips its reduce pass over dx and z)
-            sc, sh, mu, rs, _ = ctx.bn
-            part = _f32(nb * Cp * 2, x_t.device)
-            with _span("maxpool_bwd", 0.0, nbytes * B * H * W * C * _es(dtype)):
-                _lib.call("segk_maxpool2x2_bwd_bnstat", px, pdy, pdx, B, H, W, Cp, acc, sc.data_ptr(), sh.data_ptr(),
-                          mu.data_ptr(), rs.data_ptr(), part.data_ptr(), _DT[dtype], _stream())
-            dx._segk_bn_part = (part, nb, (sc.data_ptr(), B * H * W, Cp, dx._version))
-            return dx, None, None
-        with _span("maxpool_bwd", 0.0, nbytes * B * H * W * C * _es(dtype)):
-            _lib.call("segk_maxpool2x2_bwd", px, pdy, pdx, B, H, W, Cp, acc, _DT[dtype], _stream())
-        return dx, None, None
-
-
 class ConvT2x2Fn(torch.autograd.Function):
     """nn.ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) -- reference unet/unet.py:59, clip/clipunet.py:83.
     Non-overlapping, so forward is one GEMM [P x Cin].[Cin x 4Cout] with a pixel-shuffle store."""
@@ -664,22 +820,10 @@ class ConvT2x2Fn(torch.autograd.Function):
     def forward(ctx, mod, x, w, b):
         dtype = mod.compute_dtype or _compute_dtype
         _require_cuda(x, "ConvTranspose2d")
-        dev = x.device
         B, Cin, H, W = x.shape
         Cout = w.shape[1]
-        Cinp, Coutp = pad32(Cin), pad32(Cout)
         x_t, px, _ = _raw(x, dtype)
-        wp = mod.cache.get(("tf", dtype), w, lambda: pack_convt(w, dtype, 0))
-
-        def bias4():
-            t = torch.zeros((4, Coutp), dtype=torch.float32, device=dev)
-            t[:, :Cout] = _param_f32(b)
-            return t
-        b4 = None if b is None else mod.cache.get(("tb", dtype), b, bias4)
-        out = torch.empty((B, 2 * H, 2 * W, Coutp), dtype=dtype, device=dev)
-        with _span("convt_fwd", 2.0 * B * H * W * Cin * 4 * Cout, B * H * W * (Cin + 4 * Cout) * _es(dtype)):
-            _lib.call("segk_convt2x2_fwd", px, wp.data_ptr(), _p(b4), out.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
-                      _stream())
+        out = _convt_fwd(mod, x_t, px, w, b, B, H, W, Cin, Cout, dtype, x.device)
         ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, Cin, Cout)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x_t, w)
@@ -688,27 +832,10 @@ class ConvT2x2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x_t, w = ctx.saved_tensors
-        mod, dtype = ctx.mod, ctx.dtype
         B, H, W, Cin, Cout = ctx.dims
-        dev = x_t.device
-        Cinp, Coutp = pad32(Cin), pad32(Cout)
-        d_t, pd, _ = _raw(dout, dtype)
-        px = act_info(x_t, dtype)[0]
-        dx = None
-        if ctx.needs_input_grad[1]:
-            wd = mod.cache.get(("td", dtype), w, lambda: pack_convt(w, dtype, 1))
-            dxb = torch.empty((B, H, W, Cinp), dtype=dtype, device=dev)
-            with _span("convt_dgrad", 2.0 * B * H * W * Cin * 4 * Cout, B * H * W * (Cin + 4 * Cout) * _es(dtype)):
-                _lib.call("segk_convt2x2_dgrad", pd, wd.data_ptr(), dxb.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
-                          _stream())
-            dx = act_view(dxb, Cin)
-        slabs, S = wgrad(px, Cinp, pd, Coutp, 0, 0, B, H, W, 2, dtype, dev, alg=(Cin, Cout))
-        dw = wgrad_to_param(slabs, S, w.shape, Cin, Cout, 0, 4, dev)
-        db = None
-        if ctx.has_bias:     # per-channel sum of dout: handed over by the producing conv when it already has it
-            db = getattr(dout, "_segk_channel_sum", None)
-            if db is None or db.shape != (Cout,):
-                db = channel_sum(pd, B * 4 * H * W, Cout, dtype, dev)
+        d_t, pd, _ = _raw(dout, ctx.dtype)
+        dx, dw, db = _convt_bwd(ctx.mod, x_t, w, pd, B, H, W, Cin, Cout, ctx.dtype, x_t.device, ctx.needs_input_grad[1],
+                                ctx.has_bias)
         return None, dx, dw, db
 
 
@@ -754,7 +881,7 @@ class Conv1x1Fn(torch.autograd.Function):
             _lib.call("segk_conv1x1", pd, wd.data_ptr(), 0, dxb.data_ptr(), B, H, W, Coutp, Cinp, _DT[dtype], _stream())
             dx = act_view(dxb, Cin)
         slabs, S = wgrad(pd, Coutp, px, Cinp, 0, 0, B, H, W, 1, dtype, dev)
-        dw = wgrad_to_param(slabs, S, w.shape, Cout, Cin, 0, 1, dev)
+        dw = wgrad_to_param(slabs, S, w.shape, Cout, Cin, 0, 1, dev, param=w)
         db = channel_sum(pd, B * H * W, Cout, dtype, dev) if ctx.has_bias else None
         return None, dx, dw, db
 
@@ -806,7 +933,7 @@ class Conv3x3Fn(torch.autograd.Function):
             conv3x3(d_t, pd, Coutp, 0, 0, wd, dxb.data_ptr(), Cinp, 0, 0, B, H, W, dtype, alg=(Cout, Cin))
             dx = act_view(dxb, Cin)
         slabs, S = wgrad(pd, Coutp, px, Cinp, 0, 0, B, H, W, 0, dtype, dev, alg=(Cout, Cin))
-        dw = wgrad_to_param(slabs, S, w.shape, Cout, Cin, 0, 9, dev)
+        dw = wgrad_to_param(slabs, S, w.shape, Cout, Cin, 0, 9, dev, param=w)
         db = channel_sum(pd, B * H * W, Cout, dtype, dev) if ctx.has_bias else None
         return None, dx, dw, db
 
@@ -840,59 +967,29 @@ class BilinearFn(torch.autograd.Function):
 
 class HeadFn(torch.autograd.Function):
     """Output nn.Conv2d(C, num_classes, 1) -- reference unet/unet.py:91,105; clip/clipunet.py:181,187.
-    Returns fp32 NCHW logits exactly like the reference module does."""
+    Returns fp32 NCHW logits exactly like the reference module does.  (Behind a DoubleConv block the models pass the
+    head INTO that block's autograd node instead -- ops.double_conv(head=...) -- so that the head backward can accumulate
+    the block's BatchNorm reductions; this stand-alone form is the plain layer.)"""
 
     @staticmethod
     def forward(ctx, mod, x, w, b):
         dtype = mod.compute_dtype or _compute_dtype
         _require_cuda(x, "output Conv2d")
-        dev = x.device
         B, C, H, W = x.shape
-        ncls = w.shape[0]
-        if ncls > _lib.MAX_CLASSES:
-            raise RuntimeError(f"output head supports up to {_lib.MAX_CLASSES} classes, got {ncls}")
         x_t, px, Cp = _raw(x, dtype)
-        w2 = _param_f32(w).reshape(ncls, C)
-        logits = torch.empty((B, ncls, H, W), dtype=torch.float32, device=dev)
-        with _span("head_fwd", 2.0 * B * H * W * C * ncls, B * H * W * (C * _es(dtype) + 4 * ncls)):
-            _lib.call("segk_head_fwd", px, w2.data_ptr(), _param_f32(b).data_ptr(), logits.data_ptr(), B, H, W, Cp, C,
-                      ncls, _DT[dtype], _stream())
-        ctx.dtype, ctx.dims = dtype, (B, C, H, W, ncls)
+        logits = _head_fwd(px, Cp, w, b, B, C, H, W, dtype, x.device)
+        ctx.dtype, ctx.dims = dtype, (B, C, H, W)
         ctx.save_for_backward(x_t, w)
-        bn = getattr(x, "_segk_bn2", None)        # the producing DoubleConv block's BN2 vectors (training mode)
-        ctx.bn = bn if (bn is not None and bn[4] == dtype and bn[0].numel() == Cp) else None
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         x_t, w = ctx.saved_tensors
         dtype = ctx.dtype
-        B, C, H, W, ncls = ctx.dims
-        dev = x_t.device
+        B, C, H, W = ctx.dims
         px, Cp = act_info(x_t, dtype)
-        dl = dlogits
-        if dl.dtype != torch.float32 or not dl.is_contiguous():
-            dl = dl.float().contiguous()
-        w2 = _param_f32(w).reshape(ncls, C)
-        dy = torch.empty((B, H, W, Cp), dtype=dtype, device=dev)
-        part = _f32(_lib.query("segk_head_part_floats", B * H * W, Cp), dev)
-        dw = torch.empty(w.shape, dtype=torch.float32, device=dev)
-        db = _f32(ncls, dev)
-        dyv = act_view(dy, C)
-        with _span("head_bwd", 4.0 * B * H * W * C * ncls, B * H * W * (2 * C * _es(dtype) + 4 * ncls)):
-            if ctx.bn is not None and FUSE_BN_REDUCE:
-                # dy is the complete gradient of the last block's output: accumulate its BN2 backward reductions here
-                sc, sh, mu, rs, _ = ctx.bn
-                nb = _lib.query("segk_head_bwd_blocks", B * H * W)
-                bnpart = _f32(nb * Cp * 2, dev)
-                _lib.call("segk_head_bwd_bnstat", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(),
-                          dw.data_ptr(), db.data_ptr(), B, H, W, Cp, C, ncls, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
-                          rs.data_ptr(), bnpart.data_ptr(), _DT[dtype], _stream())
-                dyv._segk_bn_part = (bnpart, nb, (sc.data_ptr(), B * H * W, Cp, dyv._version))
-            else:
-                _lib.call("segk_head_bwd", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(), dw.data_ptr(),
-                          db.data_ptr(), B, H, W, Cp, C, ncls, _DT[dtype], _stream())
-        return None, dyv, dw, db
+        dy, dw, db, _ = _head_bwd(dlogits, px, Cp, w, B, C, H, W, dtype, x_t.device)
+        return None, act_view(dy, C), dw, db
 
 
 class SegLossFn(torch.autograd.Function):

@@ -39,8 +39,36 @@ def _accumulate(agg, pred, label):
 
 
 def _say(*a):
-    if VERBOSE:
+    if VERBOSE and _rank_world()[0] == 0:
         print(*a)
+
+
+def _rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _reduce_eval(total_loss, num_images, agg, device):
+    """Data-parallel evaluation: sum the loss, the image count and the aggregator's TP/FP/FN/TN over the ranks, so that
+    every rank holds the same epoch metrics (and takes the same "improved?" decision).  Correct both when the validation
+    set is sharded over the ranks and when every rank walks all of it (every count is then multiplied by the world
+    size, which cancels in the loss average and in IoU / Dice / accuracy)."""
+    import torch.distributed as dist
+    flush = getattr(agg, "flush", None)
+    if flush is not None:
+        flush()
+    C = agg.get_num_classes()
+    dev = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.zeros(2 + 4 * C, dtype=torch.float64, device=dev)
+    t[0], t[1] = total_loss, num_images
+    t[2:] = torch.cat([agg.total_tp, agg.total_fp, agg.total_fn, agg.total_tn]).to(dev)
+    dist.all_reduce(t)
+    t = t.cpu()
+    for i, name in enumerate(("total_tp", "total_fp", "total_fn", "total_tn")):
+        getattr(agg, name).copy_(t[2 + i * C:2 + (i + 1) * C])
+    return t[0].item(), int(round(t[1].item()))
 
 
 def train_loop(dataloader, model, loss_fn, optimizer, accumulation_steps, device, scheduler=None, target_size=None,
@@ -88,7 +116,7 @@ def train_loop(dataloader, model, loss_fn, optimizer, accumulation_steps, device
     return avg_loss
 
 
-def eval_loop(dataloader, model, loss_fn, device, target_size, agg):
+def eval_loop(dataloader, model, loss_fn, device, target_size, agg, grad_sync=None):
     """training.py:67-121: resize+pad -> model (eval mode, no_grad) -> reverse resize -> per-image loss at
     the ORIGINAL size and confusion counts.  Returns (avg_loss, mean_dice, mean_iou)."""
     model.eval()
@@ -122,6 +150,8 @@ def eval_loop(dataloader, model, loss_fn, device, target_size, agg):
 
     if total_dev is not None:
         total_loss += total_dev.item()  # float64 sum of the float32 losses, as the reference's `+= loss.item()` builds
+    if grad_sync is not None and _rank_world()[1] > 1:
+        total_loss, num_images_processed = _reduce_eval(total_loss, num_images_processed, agg, device)
     avg_loss = total_loss / num_images_processed
 
     mean_dice, mean_iou, mean_acc = agg.compute_epoch_metrics()
@@ -189,7 +219,7 @@ def train_loop_prompt(dataloader, model, loss_fn, optimizer, accumulation_steps,
     return avg_loss
 
 
-def eval_loop_prompt(dataloader, model, loss_fn, device, target_size, agg):
+def eval_loop_prompt(dataloader, model, loss_fn, device, target_size, agg, grad_sync=None):
     """training.py:242-296: eval_loop for (image, heat-map, label) batches; the heat-map takes the image's
     resize + pad.  Returns (avg_loss, mean_dice, mean_iou)."""
     model.eval()
@@ -223,6 +253,8 @@ def eval_loop_prompt(dataloader, model, loss_fn, device, target_size, agg):
 
     if total_dev is not None:
         total_loss += total_dev.item()  # float64 sum of the float32 losses, as the reference's `+= loss.item()` builds
+    if grad_sync is not None and _rank_world()[1] > 1:
+        total_loss, num_images_processed = _reduce_eval(total_loss, num_images_processed, agg, device)
     avg_loss = total_loss / num_images_processed
 
     mean_dice, mean_iou, mean_acc = agg.compute_epoch_metrics()
@@ -282,6 +314,10 @@ def _start(
     best_dev_dice = -np.inf
     best_dev_miou = -np.inf
     best_dev_loss = np.inf
+    # data parallel (grad_sync given, one process per GPU): every rank loads the same checkpoint, rank 0's BatchNorm
+    # running statistics are broadcast before evaluation (they are per replica during training), the evaluation
+    # counts are summed over the ranks so that all ranks take the same decision, and ONLY rank 0 writes files.
+    rank, world = _rank_world()
 
     os.makedirs(model_save_dir, exist_ok=True)
     os.makedirs(f"{model_save_dir}/metrics", exist_ok=True)
@@ -326,14 +362,20 @@ def _start(
         tl, el = (train_loop_prompt, eval_loop_prompt) if prompt else (train_loop, eval_loop)
         tl(train_dataloader, model, train_loss_fn, optimizer, accumulation_steps, device, scheduler, target_size,
            grad_sync=grad_sync)
-        val_loss, val_dice, val_miou = el(val_dataloader, model, val_loss_fn, device, target_size, agg)
+        if grad_sync is not None:
+            grad_sync.broadcast_buffers(model)
+            val_loss, val_dice, val_miou = el(val_dataloader, model, val_loss_fn, device, target_size, agg,
+                                              grad_sync=grad_sync)
+        else:
+            val_loss, val_dice, val_miou = el(val_dataloader, model, val_loss_fn, device, target_size, agg)
+        writer = save and rank == 0
 
-        if save:
+        if writer:
             torch.save({"epoch": t + 1, "history": agg}, f"{model_save_dir}/metrics/{model_save_name}")
 
         if val_miou > best_dev_miou:
             best_dev_dice, best_dev_miou, best_dev_loss = val_dice, val_miou, val_loss
-            if save:
+            if writer:
                 _say(f"Validation IoU score improved ({best_dev_miou:.6f}). Saving model...")
                 checkpoint = {
                     "epoch": t + 1,
@@ -354,6 +396,9 @@ def _start(
                                f"{model_save_dir}/MO_{model_save_name}")
         else:
             _say(f"Validation IoU score did not improve from {best_dev_miou:.6f}")
+        if world > 1 and save:
+            import torch.distributed as dist
+            dist.barrier()                # nobody reads or overwrites a file rank 0 is still writing
 
     _say("\n--- Training Finished! ---")
     _say(f"Best validation IoU score achieved: {best_dev_miou:.6f}")

@@ -39,14 +39,17 @@ class DoubleConvReLU(_FusedBase):
     def bn_modules(self):
         return self.doubleConvReLU[1], self.doubleConvReLU[4]
 
-    def forward(self, x, x_second=None):
-        """x_second: optional second operand of a channel concat [x | x_second] (used by Up)."""
+    def forward(self, x, x_second=None, emit_pool=False, head=None, upsample_from=None):
+        """The reference call is forward(x).  Extensions used by the models of this package, all explicit:
+        x_second: second operand of a channel concat [x | x_second];
+        upsample_from=(module, x2): the second concat operand is module.upsample(x2) (ConvTranspose2d), computed inside
+        this block's autograd node (Up);
+        emit_pool: also return MaxPool2d(2,2) of the output -> (y, pooled) (the next Down block's pooling);
+        head: an nn.Conv2d(C, classes, 1) applied to the output -> returns the fp32 logits instead of y."""
         s = self.doubleConvReLU
-        y = ops.DoubleConvFn.apply(self, x, x_second, s[0].weight, s[0].bias, s[1].weight, s[1].bias,
-                                   s[3].weight, s[3].bias, s[4].weight, s[4].bias)
-        y._segk_bn2 = self.__dict__.pop("_bn2_vectors", None)   # for a pooling layer behind this block (Down)
-        y._segk_pooled = self.__dict__.pop("_pooled_output", None)
-        return y
+        params = (s[0].weight, s[0].bias, s[1].weight, s[1].bias, s[3].weight, s[3].bias, s[4].weight, s[4].bias)
+        up_mod, up_x = upsample_from if upsample_from is not None else (None, None)
+        return ops.double_conv(self, x, x_second, params, emit_pool=emit_pool, head=head, up_mod=up_mod, up_x=up_x)
 
 
 class Down(nn.Module):
@@ -57,15 +60,14 @@ class Down(nn.Module):
             DoubleConvReLU(din, dout),
         )
 
-    def forward(self, x, return_skip=False):
-        """return_skip: also return an alias of x to be used as the skip connection, so that the pooling backward
-        adds its routed gradient straight into the skip gradient (one kernel instead of pool-backward + add)."""
+    def forward(self, x, pooled=None, emit_pool=False):
+        """The reference call is forward(x).  pooled: MaxPool2d(2,2)(x) when the block that produced x already emitted it
+        (DoubleConvReLU.forward(emit_pool=True): its backward then also routes the pooled gradient into the skip
+        gradient and accumulates its BatchNorm reductions in one kernel); emit_pool: see DoubleConvReLU.forward."""
         dc = self.maxpool_doubleConv[1]
-        dtype = dc.compute_dtype or ops.get_compute_dtype()
-        if return_skip:
-            p, skip = ops.MaxPoolSkipFn.apply(x, dtype, getattr(x, "_segk_bn2", None))
-            return dc(p), skip
-        return dc(ops.MaxPoolFn.apply(x, dtype))
+        if pooled is None:
+            pooled = ops.MaxPoolFn.apply(x, dc.compute_dtype or ops.get_compute_dtype())
+        return dc(pooled, emit_pool=emit_pool)
 
 
 class Up(_FusedBase):
@@ -74,12 +76,11 @@ class Up(_FusedBase):
         self.upsample = nn.ConvTranspose2d(din, dout, kernel_size=2, stride=2)
         self.doubleConv = DoubleConvReLU(din, dout)
 
-    def forward(self, x1, x2):
-        u = ops.ConvT2x2Fn.apply(self, x2, self.upsample.weight, self.upsample.bias)
-        if u.shape[2:] != x1.shape[2:]:
-            raise RuntimeError(f"Sizes of tensors must match except in dimension 1: {tuple(x1.shape)} vs "
-                               f"{tuple(u.shape)} (H and W must be multiples of 16)")
-        return self.doubleConv(x1, u)       # concat [x1 | u] consumed in place by the first conv
+    def forward(self, x1, x2, head=None):
+        """cat([x1, upsample(x2)]) -> DoubleConv (unet.py:62-64): ConvTranspose2d and DoubleConv run in ONE autograd node
+        (the concat is consumed in place by the first conv; the concat gradient's channel sums are the ConvTranspose
+        bias gradient).  head: see DoubleConvReLU.forward."""
+        return self.doubleConv(x1, head=head, upsample_from=(self, x2))
 
 
 class unet(_FusedBase):
@@ -99,11 +100,6 @@ class unet(_FusedBase):
         self.up4 = Up(self.scale * 128, self.scale * 64)
 
         self.output = nn.Conv2d(self.scale * 64, dout, kernel_size=1)
-        # the outputs of down1..down4 are pooled by the next Down block (forward below): those blocks emit the pooled
-        # tensor in the same pass as their final BN+ReLU
-        for blk in (self.down1, self.down2.maxpool_doubleConv[1], self.down3.maxpool_doubleConv[1],
-                    self.down4.maxpool_doubleConv[1]):
-            blk._emit_pool = True
 
     def set_compute_dtype(self, dtype):
         """Per-model override of ops.set_compute_dtype (torch.float32 parity mode / torch.bfloat16)."""
@@ -117,15 +113,15 @@ class unet(_FusedBase):
             return self._forward(x)
 
     def _forward(self, x):
-        x1 = self.down1(x)
-        x2, s1 = self.down2(x1, return_skip=True)     # s1..s4 alias x1..x4 (the skip connections, unet.py:96-103)
-        x3, s2 = self.down3(x2, return_skip=True)
-        x4, s3 = self.down4(x3, return_skip=True)
-        x5, s4 = self.down5(x4, return_skip=True)
+        # the outputs of down1..down4 are pooled by the next Down block (unet.py:40) AND used as skip connections
+        # (:96-103): those blocks emit the pooled tensor in the same pass as their final BN+ReLU
+        x1, p1 = self.down1(x, emit_pool=True)
+        x2, p2 = self.down2(x1, pooled=p1, emit_pool=True)
+        x3, p3 = self.down3(x2, pooled=p2, emit_pool=True)
+        x4, p4 = self.down4(x3, pooled=p3, emit_pool=True)
+        x5 = self.down5(x4, pooled=p4)
 
-        x = self.up1(s4, x5)
-        x = self.up2(s3, x)
-        x = self.up3(s2, x)
-        x = self.up4(s1, x)
-
-        return ops.HeadFn.apply(self, x, self.output.weight, self.output.bias)
+        x = self.up1(x4, x5)
+        x = self.up2(x3, x)
+        x = self.up3(x2, x)
+        return self.up4(x1, x, head=self.output)      # output 1x1 conv inside up4's autograd node (unet.py:105)

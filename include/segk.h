@@ -31,6 +31,9 @@ extern "C" {
 typedef void* segk_stream_t; /* hipStream_t */
 
 int segk_version(void);
+/* first 16 hex digits of the sha256 over the sources this library was built from (image_segmentation_amd/build.py:
+ * source_hash) -- lets a host check that a shipped libsegk.so matches the sources beside it */
+const char* segk_build_id(void);
 const char* segk_last_error(void);
 
 /* ---- layout ------------------------------------------------------------------------------------ */

@@ -24,8 +24,10 @@ def header_protos():
 @pytest.fixture(scope="module")
 def lib():
     from image_segmentation_amd import build, _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        build.build(verbose=False)
+    stamp = os.path.join(os.path.dirname(_lib.LIB_PATH), ".build_id")
+    built = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if not os.path.exists(_lib.LIB_PATH) or built != build.source_hash():
+        build.build(verbose=False)          # incremental: only what changed (before the library is first loaded)
     return _lib
 
 
@@ -49,7 +51,7 @@ def test_ctypes_table_matches_header(lib):
 
 def test_load_and_version(lib):
     so = lib.load()
-    assert so.segk_version() >= 100
+    assert so.segk_version() >= 200
     assert so.segk_last_error() is not None
     # pure size queries work without a GPU
     assert lib.query("segk_conv_tiles", 2, 32, 32, 256, 64, 1) == 2 * 2 * 1    # 16x32 tiles: bf16 64-ch output, long K
@@ -58,6 +60,13 @@ def test_load_and_version(lib):
     assert lib.query("segk_conv_tiles", 2, 32, 32, 128, 128, 1) == 2 * 4 * 1   # 8x32 tiles for 128 channels
     assert lib.query("segk_bn_stats_floats", 4, 64) == 4 * 64 * 2 + 32 * 64 * 4
     assert lib.query("segk_loss_state_floats") >= 4 + 3 * 8
+
+
+def test_library_was_built_from_the_sources_in_tree(lib):
+    """segk_build_id() is the source hash compiled into api.o: a stale libsegk.so (built from other sources than the
+    ones shipped beside it) fails here instead of silently running old kernels."""
+    from image_segmentation_amd import build
+    assert lib.build_id() == build.source_hash()
 
 
 def test_missing_library_fails_loudly(lib, monkeypatch):

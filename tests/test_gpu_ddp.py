@@ -1,0 +1,40 @@
+"""GPU: data-parallel step == mean of the single-process steps, on the real unet(3,3) through the HIP kernels
+(2 ranks sharing cuda:0 over gloo; see tests/ddp_worker.py).  SURVEY.md section 4 tier iii."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_check(dtype, out_prefix):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), "2", str(port), dtype,
+                               out_prefix], env=env) for r in range(2)]
+    rcs = [p.wait(timeout=600) for p in procs]
+    res = [json.load(open(f"{out_prefix}.rank{r}.json")) for r in range(2)]
+    return rcs, res
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_data_parallel_step_equals_mean_of_single_process_steps(dtype, tmp_path):
+    rcs, res = run_check(dtype, str(tmp_path / "ddp"))
+    for r in res:
+        assert "error" not in r, r["error"]
+        assert r["ok"], r
+        assert r["replicas_identical"]
+        for acc in ("acc1", "acc2"):
+            assert r["worst_rel_l2"][acc][1] <= 1e-5, r["worst_rel_l2"]
+        assert r["acc1_in_bucket"][0] == r["acc1_in_bucket"][1]      # after sync every .grad lives in its bucket
+        # the 18 3x3 and 4 transposed-conv weight gradients were WRITTEN there by the weight-gradient kernels (no copy)
+        assert r["acc1_direct"] >= 22, r
+    assert rcs == [0, 0]

@@ -290,8 +290,9 @@ def test_bn_reductions_fused_into_pool_and_head_backward(seg, dtype):
 
 
 def test_fused_bn_reductions_survive_extra_consumers(seg):
-    """A block output that ALSO feeds a third consumer gets its gradient summed by autograd after the pooling backward
-    ran: the partial sums accumulated there are stale and must not be used (version / identity guard)."""
+    """A block output that feeds the next block's pooling AND two more consumers: autograd sums the other consumers'
+    gradients before the block's node runs, the pooling backward inside that node then completes the gradient and
+    accumulates the BatchNorm reductions over exactly what it wrote -- same gradients as the unfused path."""
     from image_segmentation_amd import ops
     seg.set_compute_dtype(torch.float32)
     x = fill((2, 3, 32, 32), 1, 0, 1).cuda()
@@ -301,13 +302,55 @@ def test_fused_bn_reductions_survive_extra_consumers(seg):
         dc = seg.DoubleConvReLU(3, 64); down = seg.Down(64, 128)
         fill_module(dc, 1000); fill_module(down, 2000)
         dc.cuda().train(); down.cuda().train()
-        y = dc(x)
-        p, skip = down(y, return_skip=True)
-        loss = p.float().sum() * 0.3 + (skip.float() * fill(tuple(skip.shape), 7, -1, 1).cuda()).sum() + (y.float() ** 2).sum() * 0.1
+        y, pooled = dc(x, emit_pool=True)
+        p = down(y, pooled=pooled)
+        loss = p.float().sum() * 0.3 + (y.float() * fill(tuple(y.shape), 7, -1, 1).cuda()).sum() + (y.float() ** 2).sum() * 0.1
         loss.backward()
         grads.append({n: q.grad.float().clone() for n, q in dc.named_parameters()})
     ops.FUSE_BN_REDUCE = True
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         assert (a - b).norm() <= 2e-4 * b.norm() + 1e-6, (n, (a - b).norm().item(), b.norm().item())
+    seg.set_compute_dtype(torch.bfloat16)
+
+
+def test_two_forwards_then_two_backwards_keep_their_own_state(seg):
+    """Everything the fused backward kernels hand to each other lives in the autograd node of ONE forward call: two
+    training forwards (different inputs) followed by their two backwards in either order, with a forward under
+    torch.no_grad() and an eval() forward in between, give the gradients of two separate runs -- fused and unfused."""
+    from image_segmentation_amd import ops
+    seg.set_compute_dtype(torch.float32)
+    Xa = fill((2, 3, 32, 48), 1, 0, 1).cuda(); Ya = labels((2, 32, 48), 2, 3).cuda()
+    Xb = fill((2, 3, 32, 48), 3, 0, 1).cuda(); Yb = labels((2, 32, 48), 4, 3).cuda()
+    loss_fn = seg.CrossEntropyLoss()
+
+    def fresh():
+        m = seg.unet(3, 3); fill_module(m, 1000); return m.cuda().train()
+
+    def grads_of(m):
+        return {n: p.grad.float().clone() for n, p in m.named_parameters()}
+    ops.FUSE_BN_REDUCE = False
+    want = {}
+    for key, (X, Y) in (("a", (Xa, Ya)), ("b", (Xb, Yb))):
+        m = fresh(); loss_fn(m(X), Y).backward(); want[key] = grads_of(m)
+    ops.FUSE_BN_REDUCE = True
+    for order in ("ab", "ba"):
+        m = fresh()
+        la = loss_fn(m(Xa), Ya)
+        with torch.no_grad():
+            m(Xb)                                   # a forward that will never be differentiated
+        lb = loss_fn(m(Xb), Yb)
+        m.eval()
+        with torch.no_grad():
+            m(Xa)
+        m.train()
+        got = {}
+        for key in order:
+            m.zero_grad(set_to_none=True)
+            (la if key == "a" else lb).backward()
+            got[key] = grads_of(m)
+        for key in "ab":
+            for n in want[key]:
+                a, b = got[key][n], want[key][n]
+                assert (a - b).norm() <= 2e-4 * b.norm() + 1e-7, (order, key, n, (a - b).norm().item(), b.norm().item())
     seg.set_compute_dtype(torch.bfloat16)
