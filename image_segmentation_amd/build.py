@@ -9,7 +9,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["api.hip", "conv_igemm.hip", "wgrad.hip", "bn_pool.hip", "pack.hip", "head_loss.hip", "resize.hip", "vit.hip", "gemm.hip"]
+SOURCES = ["api.hip", "conv_igemm.hip", "conv_rs.hip", "wgrad.hip", "bn_pool.hip", "pack.hip", "head_loss.hip", "resize.hip", "vit.hip", "gemm.hip"]
 LIB = os.path.join(CSRC, "libsegk.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -75,6 +75,50 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with open(stamp, "w") as f:
         f.write(bid + "\n")
     return LIB
+
+
+def build_sanitized(verbose: bool = False) -> str:
+    """Host-side AddressSanitizer + UndefinedBehaviorSanitizer build of the library (device code is compiled as usual:
+    GPU sanitizers are not available on this pool) -> csrc/.asan/libsegk_asan.so, rebuilt when the source hash moves.
+    Used by tests/test_abi_hardening.py, which drives every C-ABI entry with invalid arguments on the CPU box."""
+    hipcc = _hipcc()
+    out = os.path.join(CSRC, ".asan")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, "libsegk_asan.so")
+    stamp = os.path.join(out, ".build_id")
+    bid = source_hash()
+    if os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == bid:
+        return lib
+    flags = ["--offload-arch=gfx950", "-O1", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-omit-frame-pointer",
+             "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize"]
+    objs, jobs = [], []
+    for s in SOURCES:
+        obj = os.path.join(out, s.replace(".hip", ".o"))
+        objs.append(obj)
+        extra = [f'-DSEGK_BUILD_ID="{bid}"'] if s == "api.hip" else []
+        jobs.append([hipcc, *flags, *extra, "-c", os.path.join(CSRC, s), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan", "-o", lib, *objs])
+    with open(stamp, "w") as f:
+        f.write(bid + "\n")
+    return lib
+
+
+def asan_runtime() -> str:
+    """The shared AddressSanitizer runtime to LD_PRELOAD into an uninstrumented python."""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not hits:
+        raise RuntimeError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+    return hits[-1]
 
 
 if __name__ == "__main__":

@@ -36,6 +36,23 @@ int segk_loss_bwd_impl(const float*, const long long*, const float*, const float
 int segk_prompt_mix_impl(const float*, const float*, const float*, float*, int, long, hipStream_t);
 int segk_confusion_impl(const float*, const long long*, int, int, long, unsigned long long*, hipStream_t);
 
+int segk_device_index() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev < SEGK_MAX_DEVICES ? dev : SEGK_MAX_DEVICES - 1;
+}
+int segk_num_cus() {
+  static int n[SEGK_MAX_DEVICES] = {};    // racing first calls write the same value
+  const int dev = segk_device_index();
+  if (n[dev] == 0) {
+    hipDeviceProp_t p;
+    int v = 0;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess) v = p.multiProcessorCount;
+    n[dev] = v >= 8 ? v : 256;
+  }
+  return n[dev];
+}
+
 static void fill_tiles(ConvArgs&) {}   // tile geometry is chosen per kernel configuration by the launcher
 
 extern "C" {
@@ -48,25 +65,32 @@ const char* segk_build_id(void) { return SEGK_BUILD_ID; }
 const char* segk_last_error(void) { return g_segk_err; }
 
 int segk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cp, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "nchw_to_nhwc: bad dtype %d", dtype);
   return segk_nchw_to_nhwc_impl(src, dst, B, C, H, W, Cp, dtype, (hipStream_t)s);
 }
 int segk_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cp, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "nhwc_to_nchw: bad dtype %d", dtype);
   return segk_nhwc_to_nchw_impl(src, dst, B, C, H, W, Cp, dtype, (hipStream_t)s);
 }
 int segk_pack_conv_weight(const float* w, void* dst, int Cout, int CA, int CB, int Coutp, int CAp, int CBp, int taps,
                           int mode, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "pack_conv_weight: bad dtype %d", dtype);
   return segk_pack_conv_weight_impl(w, dst, Cout, CA, CB, Coutp, CAp, CBp, taps, mode, dtype, (hipStream_t)s);
 }
 int segk_pack_conv3x3_both(const float* w, void* dst_fwd, void* dst_dgrad, int Cout, int CA, int CB, int Coutp, int CAp,
                             int CBp, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "pack_conv3x3_both: bad dtype %d", dtype);
   return segk_pack_conv3x3_both_impl(w, dst_fwd, dst_dgrad, Cout, CA, CB, Coutp, CAp, CBp, dtype, (hipStream_t)s);
 }
 int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cinp, int Coutp, int mode, int dtype,
                            segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "pack_convt_weight: bad dtype %d", dtype);
   return segk_pack_convt_weight_impl(w, dst, Cin, Cout, Cinp, Coutp, mode, dtype, (hipStream_t)s);
 }
 
 int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (long long)B * H * W > 0x1fffffffLL) return 0;
+  if (segk_conv_use_rs(Cin, Cout, dtype, W)) return segk_conv_rs_rows(B, H, W, Cout);   // one row per wave slab
   const int pk = segk_conv_use_pipe(Cin, Cout, dtype);
   const int bm = segk_conv_use_ws(Cin, Cout, dtype) ? 256 : pk ? 32768 / pk : segk_conv_bm(0, Cout);
   const int twl = segk_conv_twl(bm, W);
@@ -76,6 +100,7 @@ int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype) {
 int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const float* bias, const float* scale,
                  const float* shift, void* out, void* out2, float* stats, int B, int H, int W, int CA, int CB, int CO1,
                  int CO2, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "conv3x3: bad dtype %d", dtype);
   ConvArgs a{};
   a.srcA = srcA; a.srcB = srcB; a.w = wpacked; a.bias = bias; a.scale = scale; a.shift = shift;
   a.out = out; a.out2 = out2; a.stats = stats;
@@ -88,6 +113,7 @@ int segk_conv_writes_act_q(int Cin, int Cout, int dtype) { return segk_conv_writ
 
 int segk_conv3x3_act(const void* srcA, const void* wpacked, const float* scale, const float* shift, void* out,
                      void* act_out, float* stats, int B, int H, int W, int CA, int CO, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "conv3x3_act: bad dtype %d", dtype);
   ConvArgs a{};
   a.srcA = srcA; a.w = wpacked; a.scale = scale; a.shift = shift; a.out = out; a.act_out = act_out; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.CA = CA; a.Ntot = CO; a.CO1 = CO;
@@ -97,6 +123,7 @@ int segk_conv3x3_act(const void* srcA, const void* wpacked, const float* scale, 
 
 int segk_conv1x1(const void* srcA, const void* wpacked, const float* bias, void* out, int B, int H, int W, int CA,
                  int CO, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "conv1x1: bad dtype %d", dtype);
   ConvArgs a{};
   a.srcA = srcA; a.w = wpacked; a.bias = bias; a.out = out;
   a.B = B; a.H = H; a.W = W; a.CA = CA; a.Ntot = CO; a.CO1 = CO;
@@ -106,6 +133,7 @@ int segk_conv1x1(const void* srcA, const void* wpacked, const float* bias, void*
 
 int segk_linear(const void* rows, const void* wpacked, const float* bias, void* out, long M, int K, int N, int act,
                 int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "linear: bad dtype %d", dtype);
   // [M][K] x [K][N] (+ bias, optional quick_gelu): the 1x1-convolution GEMM over a 16-pixel-wide strip of M/16 rows
   SEGK_REQUIRE(M > 0 && M % 16 == 0 && M / 16 < (1 << 24), "linear: M=%ld must be a positive multiple of 16", M);
   SEGK_REQUIRE(act == 0 || act == 1, "linear: bad activation %d", act);
@@ -118,6 +146,7 @@ int segk_linear(const void* rows, const void* wpacked, const float* bias, void* 
 
 int segk_linear_splitk(const void* rows, const void* wpacked, const float* bias, void* out_parts, long M, int K, int N,
                        int ksplit, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "linear_splitk: bad dtype %d", dtype);
   // bf16 only: `ksplit` partial products [ksplit][M][N] (the consumer sums them: segk_add_layernorm_parts)
   SEGK_REQUIRE(dtype == SEGK_DT_BF16, "linear_splitk: bf16 only");
   SEGK_REQUIRE(M > 0 && M % 16 == 0 && K > 0 && K % 64 == 0 && N > 0 && ksplit >= 1, "linear_splitk: bad shape");
@@ -132,6 +161,7 @@ int segk_linear_splitk(const void* rows, const void* wpacked, const float* bias,
 
 int segk_convt2x2_fwd(const void* in, const void* wpacked, const float* bias4, void* out, int B, int H, int W, int Cin,
                       int Cout, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "convt2x2_fwd: bad dtype %d", dtype);
   // bias4: per-N bias of length 4*Cout (the layer bias repeated for the four taps) or NULL
   ConvArgs a{};
   a.srcA = in; a.w = wpacked; a.bias = bias4; a.out = out;
@@ -142,6 +172,7 @@ int segk_convt2x2_fwd(const void* in, const void* wpacked, const float* bias4, v
 
 int segk_convt2x2_dgrad(const void* dout, const void* wpacked, void* din, int B, int H, int W, int Cin, int Cout,
                         int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "convt2x2_dgrad: bad dtype %d", dtype);
   ConvArgs a{};
   a.srcA = dout; a.w = wpacked; a.out = din;
   a.B = B; a.H = H; a.W = W; a.CA = Cout; a.Ntot = Cin; a.CO1 = Cin; a.unshuf = 1;
@@ -152,6 +183,7 @@ int segk_convt2x2_dgrad(const void* dout, const void* wpacked, void* din, int B,
 int segk_wgrad(const void* dz, const void* srcA, const void* srcB, const float* scale, const float* shift, float* slabs,
                const void* zeros, int S, int B, int H, int W, int CD, int CA, int CB, int geo, int dtype,
                segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "wgrad: bad dtype %d", dtype);
   WgradArgs a{};
   a.dz = dz; a.srcA = srcA; a.srcB = srcB; a.scale = scale; a.shift = shift; a.slabs = slabs; a.zeros = zeros;
   a.B = B; a.H = H; a.W = W; a.CD = CD; a.CA = CA; a.CB = CB; a.S = S;
@@ -170,45 +202,55 @@ int segk_bn_finalize(const float* stats, int tiles, int Cp, int C, double count,
 }
 int segk_bn_relu_apply(const void* z, void* y, const float* scale, const float* shift, long P, int Cp, int dtype,
                        segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "bn_relu_apply: bad dtype %d", dtype);
   return segk_bn_relu_apply_impl(z, y, scale, shift, P, Cp, dtype, (hipStream_t)s);
 }
 int segk_bn_relu_apply_pool(const void* z, void* y, void* pooled, const float* scale, const float* shift, int B, int H, int W,
                             int Cp, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "bn_relu_apply_pool: bad dtype %d", dtype);
   return segk_bn_relu_apply_pool_impl(z, y, pooled, scale, shift, B, H, W, Cp, dtype, (hipStream_t)s);
 }
 int segk_bn_relu_bwd(const void* dy, const void* z, void* dz, const float* scale, const float* shift, const float* mean,
                      const float* rstd, long P, int Cp, int C, float* part, float* dgamma, float* dbeta, float* coef,
                      int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "bn_relu_bwd: bad dtype %d", dtype);
   return segk_bn_bwd_impl(dy, z, dz, scale, shift, mean, rstd, P, Cp, C, part, dgamma, dbeta, coef, dtype,
                           (hipStream_t)s);
 }
 int segk_channel_sum(const void* x, long P, int Cp, int C, float* part, float* out, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "channel_sum: bad dtype %d", dtype);
   return segk_channel_sum_impl(x, P, Cp, C, part, out, dtype, (hipStream_t)s);
 }
 int segk_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int Cp, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "maxpool2x2_fwd: bad dtype %d", dtype);
   return segk_maxpool_fwd_impl(x, y, B, H, W, Cp, dtype, (hipStream_t)s);
 }
 int segk_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate, int dtype,
                         segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "maxpool2x2_bwd: bad dtype %d", dtype);
   return segk_maxpool_bwd_impl(x, dy, dx, B, H, W, Cp, accumulate, dtype, (hipStream_t)s);
 }
 int segk_maxpool2x2_bwd_bnstat(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate,
                                const float* scale, const float* shift, const float* mean, const float* rstd, float* part,
                                int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "maxpool2x2_bwd_bnstat: bad dtype %d", dtype);
   return segk_maxpool_bwd_bnstat_impl(x, dy, dx, B, H, W, Cp, accumulate, scale, shift, mean, rstd, part, dtype, (hipStream_t)s);
 }
 int segk_bn_relu_bwd_from_part(const void* dy, const void* z, void* dz, const float* scale, const float* shift,
                                const float* mean, const float* rstd, long P, int Cp, int C, const float* part, int nb,
                                float* dgamma, float* dbeta, float* coef, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "bn_relu_bwd_from_part: bad dtype %d", dtype);
   return segk_bn_bwd_from_part_impl(dy, z, dz, scale, shift, mean, rstd, P, Cp, C, part, nb, dgamma, dbeta, coef, dtype,
                                     (hipStream_t)s);
 }
 int segk_head_fwd(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp, int C,
                   int ncls, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "head_fwd: bad dtype %d", dtype);
   return segk_head_fwd_impl(y, w, bias, logits, B, H, W, Cp, C, ncls, dtype, (hipStream_t)s);
 }
 int segk_head_bwd(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
                   int B, int H, int W, int Cp, int C, int ncls, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "head_bwd: bad dtype %d", dtype);
   return segk_head_bwd_impl(dlogits, y, w, dy, part, dw, db, B, H, W, Cp, C, ncls, nullptr, nullptr, nullptr, nullptr, nullptr,
                             dtype, (hipStream_t)s);
 }
@@ -216,6 +258,7 @@ int segk_head_bwd_blocks(long P) { return segk_head_blocks_q(P); }
 int segk_head_bwd_bnstat(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
                          int B, int H, int W, int Cp, int C, int ncls, const float* scale, const float* shift,
                          const float* mean, const float* rstd, float* bnpart, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "head_bwd_bnstat: bad dtype %d", dtype);
   SEGK_REQUIRE(bnpart, "head_bwd_bnstat: null partials");
   return segk_head_bwd_impl(dlogits, y, w, dy, part, dw, db, B, H, W, Cp, C, ncls, scale, shift, mean, rstd, bnpart, dtype,
                             (hipStream_t)s);

@@ -473,7 +473,11 @@ int segk_bn_finalize_impl(const float* part, int MT, int C, int C_real, double c
   SEGK_CHECK_LAUNCH("bn_finalize");
   return 0;
 }
-int segk_bn_stats_floats(int tiles, int Cp) { return tiles * Cp * 2 + NCH * Cp * 4; }
+int segk_bn_stats_floats(int tiles, int Cp) {
+  if (tiles <= 0 || Cp <= 0) return 0;
+  const long long n = (long long)tiles * Cp * 2 + (long long)NCH * Cp * 4;
+  return n > 0x7fffffffLL ? 0 : (int)n;     // sizes that do not fit an int are not served (the launch entries refuse them)
+}
 
 template <typename T>
 static int bn_relu_apply_t(const void* z, void* y, const float* scale, const float* shift, long P, int C, hipStream_t st) {
@@ -512,6 +516,7 @@ int segk_bn_relu_apply_pool_impl(const void* z, void* y, void* pooled, const flo
 }
 
 int segk_bn_bwd_blocks(long P, int C, int dtype) {
+  if (P <= 0 || C <= 0 || C % 32 != 0) return 0;      // nonsense input: no blocks (the launch entries refuse it)
   const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
   int cvb, rows, gy;
   lane_geometry(C, vec, &cvb, &rows, &gy);

@@ -24,6 +24,7 @@
 // Epilogue: optional bias, per-channel sum / sum-of-squares partials for training-mode BatchNorm taken
 // from the fp32 accumulators (deterministic per-tile partials, no atomics), LDS transpose, 16-byte
 // coalesced NHWC stores (optionally split over two destinations, or pixel-shuffled for ConvTranspose).
+#include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
 #include "segk_internal.h"
@@ -72,16 +73,7 @@ template <> struct Mma<float> {
   }
 };
 
-static int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-    if (n < 8) n = 256;
-  }
-  return n;
-}
+static int num_cus() { return segk_num_cus(); }
 
 // Tile: BM = WM*MF*32 output pixels (TH x TW, TW = 1 << TWL) by BN = WN*NF*32 output channels, WM*WN waves.
 // PBUF: patch buffers (2 = next chunk staged under the current chunk's MFMAs; 1 = smaller LDS footprint so
@@ -1086,11 +1078,12 @@ int launch_ws(ConvArgs a, hipStream_t st) {
   if (gw < NT) gw = NT;
   a.persistent = 1;
   auto kern = conv_ws_kernel<T, TWL, PRO>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[SEGK_MAX_DEVICES] = {};     // per device: the attribute is device state
+  const int dev = segk_device_index();
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SEGK_FAIL(-3, "conv_ws: cannot raise dynamic LDS limit");
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(kern, dim3(8 * gw), dim3(NTHR), lds, st, a);
   SEGK_CHECK_LAUNCH("conv_ws");
@@ -1113,11 +1106,12 @@ int launch_pipe(ConvArgs a, hipStream_t st) {
   if (gw > per_xcd) gw = per_xcd;
   a.persistent = 1;
   auto kern = conv3x3_pipe_kernel<TWL, PRO, BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[SEGK_MAX_DEVICES] = {};
+  const int dev = segk_device_index();
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SEGK_FAIL(-3, "conv3x3_pipe: cannot raise dynamic LDS limit");
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(kern, dim3(8 * gw), dim3(NTHR), lds, st, a);
   SEGK_CHECK_LAUNCH("conv3x3_pipe");
@@ -1150,11 +1144,12 @@ int launch_pro(ConvArgs a, hipStream_t st) {
   if (gw > per_xcd) gw = per_xcd;
   a.persistent = 1;
   auto kern = conv_igemm_kernel<T, GEO, TWL, WM, WN, MF, NF, PBUF, PRO>;
-  static bool attr_set = false;  // idempotent; racing setters write the same value
-  if (!attr_set) {
+  static bool attr_set[SEGK_MAX_DEVICES] = {};  // idempotent; racing setters write the same value
+  const int dev = segk_device_index();
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SEGK_FAIL(-3, "conv_igemm: cannot raise dynamic LDS limit");
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(kern, dim3(8 * gw), dim3(NTHR), lds, st, a);
   SEGK_CHECK_LAUNCH("conv_igemm");
@@ -1174,6 +1169,15 @@ int launch_geo(const ConvArgs& a, hipStream_t st) {
   // BN must divide N (with the pixel-shuffle store a tile may span taps: each thread derives its own tap)
   const int unit = a.Ntot;
   const bool wide = a.W > 16;                      // 8x32 tiles unless the image is at most 16 wide
+  if constexpr (GEO == 0 && sizeof(T) == 2) {
+    // narrow high-resolution layers, images wider than 16 pixels: register-stationary streaming kernel (conv_rs.hip)
+    if (segk_conv_use_rs(a.CA + a.CB, a.Ntot, SEGK_DT_BF16, a.W)) {
+      if (!a.bias) return segk_conv_rs_launch(a, st);
+      // a biased layer falls through to the weight-stationary kernel, whose statistics rows are per tile while
+      // segk_conv_tiles() sized the buffer for conv_rs: the combination is refused instead of overrunning it
+      SEGK_REQUIRE(!a.stats, "conv3x3: bias together with BatchNorm statistics is not served for this layer shape");
+    }
+  }
   if constexpr (GEO == 0 && sizeof(T) == 2) {
     // narrow high-resolution layers: weight-stationary streaming kernel (64-channel tiles)
     if (segk_conv_use_ws(a.CA + a.CB, a.Ntot, sizeof(T) == 2 ? SEGK_DT_BF16 : SEGK_DT_F32)) {

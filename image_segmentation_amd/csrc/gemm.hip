@@ -237,25 +237,17 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
   }
 }
 
-static int g_num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-    if (n < 8) n = 256;
-  }
-  return n;
-}
+static int g_num_cus() { return segk_num_cus(); }
 
 template <int MODE>
 int launch_mode(const GemmArgs& g, hipStream_t st) {
   auto kern = gemm_pipe_kernel<MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[SEGK_MAX_DEVICES] = {};     // per device: the attribute is device state
+  const int dev_ = segk_device_index();
+  if (!attr_set[dev_]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SEGK_FAIL(-3, "gemm_pipe: cannot raise dynamic LDS limit");
-    attr_set = true;
+    attr_set[dev_] = true;
   }
   const long U = ((g.M + G_BM - 1) / G_BM) * (g.N / G_BN) * (g.ksplit > 1 ? g.ksplit : 1);
   const int per_xcd = (int)((U + 7) / 8);

@@ -420,10 +420,15 @@ static bool raise_lds(const void* f) {
 
 // ------------------------------------------------------------------------------------------------
 int segk_head_blocks(long P) {
+  if (P <= 0) return 0;
   long g = (P + 31) / 32;
   return (int)(g > 1024 ? 1024 : g);
 }
-int segk_head_part_floats(long P, int Cp) { return segk_head_blocks(P) * MAXC * (Cp + 1); }
+int segk_head_part_floats(long P, int Cp) {
+  if (P <= 0 || Cp <= 0) return 0;
+  const long long n = (long long)segk_head_blocks(P) * MAXC * ((long long)Cp + 1);
+  return n > 0x7fffffffLL ? 0 : (int)n;
+}
 
 int segk_head_fwd_impl(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp,
                        int C, int ncls, int dtype, hipStream_t st) {
@@ -554,6 +559,7 @@ int segk_prompt_mix_impl(const float* clip, const float* mask, const float* dout
 }
 
 int segk_loss_blocks(long P) {
+  if (P <= 0) return 0;
   long g = (P + 255) / 256;
   return (int)(g > 512 ? 512 : g);
 }

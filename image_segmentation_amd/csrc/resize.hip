@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_y_kernel(const float* __rest
 extern "C" int segk_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, int OH, int OW, int Cp, int dtype,
                                  segk_stream_t s) {
   SEGK_REQUIRE(x && y && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && Cp > 0 && Cp % 32 == 0, "bilinear_fwd: bad arguments");
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "bilinear_fwd: bad dtype %d", dtype);
   const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
   long g = ((long)B * OH * OW * (Cp / vec) + 255) / 256;
   if (g > 8192) g = 8192;
@@ -179,6 +180,7 @@ extern "C" int segk_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, 
 extern "C" int segk_bilinear_bwd(const void* dy, void* dx, float* scratch, int B, int IH, int IW, int OH, int OW, int Cp,
                                  int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dy && dx && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && Cp > 0 && Cp % 32 == 0, "bilinear_bwd: bad arguments");
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "bilinear_bwd: bad dtype %d", dtype);
   const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
   if (scratch) {   // separable two-pass form: scratch holds B*OH*IW*Cp floats
     hipStream_t st2 = (hipStream_t)s;
@@ -264,6 +266,14 @@ __global__ __launch_bounds__(256) void resize_pad_kernel(const V* __restrict__ i
         sy = sy > H - 1 ? H - 1 : sy;
         sx = sx > W - 1 ? W - 1 : sx;
         v = src[(size_t)sy * W + sx];
+      } else if (mode == 2) {   // plain two-tap bilinear, align_corners=False (torchvision's tensor resize before 0.17)
+        int y0, y1, x0, x1;
+        float ly, lx;
+        src_index(oy, sh, H, y0, y1, ly);
+        src_index(ox, sw, W, x0, x1, lx);
+        const float a = (float)src[(size_t)y0 * W + x0], b = (float)src[(size_t)y0 * W + x1];
+        const float d = (float)src[(size_t)y1 * W + x0], e = (float)src[(size_t)y1 * W + x1];
+        v = (V)((1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * d + lx * e));
       } else {
         const AA ay = aa_taps(oy, sh, H), ax = aa_taps(ox, sw, W);
         float acc = 0.f;
@@ -315,8 +325,8 @@ extern "C" int segk_resize_pad(const void* img, void* out, int C, int H, int W, 
                                int pad_left, int mode, int elem, segk_stream_t s) {
   SEGK_REQUIRE(img && out && C > 0 && H > 0 && W > 0 && nh > 0 && nw > 0 && T > 0, "resize_pad: bad shape");
   SEGK_REQUIRE(pad_top >= 0 && pad_left >= 0 && pad_top + nh <= T && pad_left + nw <= T, "resize_pad: window outside the target");
-  SEGK_REQUIRE((mode == 0 || mode == 1) && (elem == 0 || elem == 1), "resize_pad: bad mode/element type");
-  SEGK_REQUIRE(!(elem == 1 && mode == 0), "resize_pad: integer images resize with mode nearest only");
+  SEGK_REQUIRE(mode >= 0 && mode <= 2 && (elem == 0 || elem == 1), "resize_pad: bad mode/element type");
+  SEGK_REQUIRE(!(elem == 1 && mode != 1), "resize_pad: integer images resize with mode nearest only");
   long g = ((long)C * T * T + 255) / 256;
   if (g > 16384) g = 16384;
   hipStream_t st = (hipStream_t)s;

@@ -24,6 +24,17 @@ struct ConvArgs {
   int act;              // 1x1 geometry only: 1 = quick_gelu on (acc + bias) (CLIP MLP fc1)
 };
 int segk_conv_igemm_launch(const ConvArgs& a, int geo, int dtype, hipStream_t st);
+
+// per-device launch state (hipFuncSetAttribute flags, CU counts) is indexed by the current device
+#define SEGK_MAX_DEVICES 64
+int segk_device_index();                  // hipGetDevice(), clamped to [0, SEGK_MAX_DEVICES)
+int segk_num_cus();                       // multiprocessor count of the current device (256 when no device is visible)
+
+// register-stationary kernel for the narrow high-resolution bf16 layers (conv_rs.hip)
+int segk_conv_use_rs(int cin_p, int n_p, int dtype, int W);
+int segk_conv_rs_rows(int B, int H, int W, int n_p);          // rows of BatchNorm partials it writes
+void segk_conv_rs_grid(int B, int H, int W, int NT, int* gw_out, int* GW_out);
+int segk_conv_rs_launch(const ConvArgs& a, hipStream_t st);
 int segk_conv_use_ws(int cin_p, int n_p, int dtype);   // weight-stationary variant applies
 int segk_conv_use_pipe(int cin_p, int n_p, int dtype); // producer/consumer variant: its channel tile (128 | 64) or 0
 int segk_conv_writes_act(int cin_p, int n_p, int dtype); // the layer's kernel can emit ConvArgs::act_out

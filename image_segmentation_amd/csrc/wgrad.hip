@@ -440,11 +440,12 @@ int launch_dma(const WgradArgs& a, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "wgrad_dma: LDS exceeds 160 KiB");
   const int NCT = (a.CD / (32 * WC)) * ((a.CA + a.CB) / (32 * WI));
   auto kern = wgrad_dma_kernel<WC, WI, PRO>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[SEGK_MAX_DEVICES] = {};     // per device: the attribute is device state
+  const int dev_ = segk_device_index();
+  if (!attr_set[dev_]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SEGK_FAIL(-3, "wgrad_dma: cannot raise dynamic LDS limit");
-    attr_set = true;
+    attr_set[dev_] = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3(256), lds, st, a);
   SEGK_CHECK_LAUNCH("wgrad_dma");
@@ -462,11 +463,12 @@ int launch_cfg(const WgradArgs& a, hipStream_t st) {
   const size_t lds = (size_t)WC * G::NDZ * G::BLKP + (size_t)WI * G::NPP * G::BLKP;
   const int NCT = (a.CD / (32 * WC)) * ((a.CA + a.CB) / (32 * WI));
   auto kern = wgrad_kernel<T, GEO, WC, WI>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[SEGK_MAX_DEVICES] = {};     // per device: the attribute is device state
+  const int dev_ = segk_device_index();
+  if (!attr_set[dev_]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SEGK_FAIL(-3, "wgrad: cannot raise dynamic LDS limit");
-    attr_set = true;
+    attr_set[dev_] = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3(256), lds, st, a);
   SEGK_CHECK_LAUNCH("wgrad");
@@ -503,7 +505,9 @@ int launch_t(const WgradArgs& a, int geo, hipStream_t st) {
 int segk_wgrad_tiles(int B, int H, int W, int geo, int dtype) {
   const bool bf = dtype == SEGK_DT_BF16;
   const int R = geo == 2 ? (bf ? 4 : 2) : (bf ? 8 : 4);
-  return B * cdiv(H, R) * cdiv(W, 16);
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  const long long n = (long long)B * cdiv(H, R) * cdiv(W, 16);
+  return n > 0x7fffffffLL ? 0 : (int)n;
 }
 
 int segk_wgrad_launch(const WgradArgs& a, int geo, int dtype, hipStream_t st) {

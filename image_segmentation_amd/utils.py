@@ -19,6 +19,12 @@ import torch.nn.functional as F
 from . import _lib
 
 BILINEAR, NEAREST = "bilinear", "nearest"
+# Bilinear down-scaling with or without the anti-aliasing (triangle) filter.  The reference calls torchvision's
+# TF.resize(image, size, interpolation=BILINEAR) on tensors (utils/utils.py:28) and pins no torchvision version:
+# from 0.17 on that call anti-aliases by default (antialias=True), before it did not (antialias=None -> False on tensors,
+# with a deprecation warning).  True reproduces a current torchvision; pass antialias=False (or set this default) to
+# reproduce an older one.  Up-scaling and nearest are unaffected.
+ANTIALIAS = True
 
 
 def _geometry(orig_h, orig_w, target_size):
@@ -38,21 +44,23 @@ def _is_cuda_device(device):
     return device is not None and torch.device(device).type == "cuda"
 
 
-def _resize_pad_into(image, slot, target_size, interpolation):
+def _resize_pad_into(image, slot, target_size, interpolation, antialias=None):
     """image (C,H,W) on the slot's device -> slot (C,T,T) (HIP kernel); returns the metadata."""
+    antialias = ANTIALIAS if antialias is None else antialias
     C, H, W = image.shape
     nh, nw, pt, pl, meta = _geometry(H, W, target_size)
     integer = not torch.is_floating_point(image)
     src = image.contiguous() if (image.dtype in (torch.float32, torch.int64)) else \
         (image.long().contiguous() if integer else image.float().contiguous())
-    mode = 1 if (interpolation == NEAREST or integer) else 0
+    mode = 1 if (interpolation == NEAREST or integer) else (0 if antialias else 2)
     _lib.call("segk_resize_pad", src.data_ptr(), slot.data_ptr(), C, H, W, nh, nw, target_size, pt, pl, mode,
               1 if integer else 0, torch.cuda.current_stream().cuda_stream)
     return meta
 
 
-def resize_with_padding(image, target_size=512, interpolation=BILINEAR):
-    """utils.py:13-49 -- (C,H,W) -> (C,target,target) plus metadata."""
+def resize_with_padding(image, target_size=512, interpolation=BILINEAR, antialias=None):
+    """utils.py:13-49 -- (C,H,W) -> (C,target,target) plus metadata.  antialias: see ANTIALIAS."""
+    antialias = ANTIALIAS if antialias is None else antialias
     _, orig_h, orig_w = image.shape
     scale = min(target_size / orig_w, target_size / orig_h)
     new_w = int(round(orig_w * scale))
@@ -61,8 +69,7 @@ def resize_with_padding(image, target_size=512, interpolation=BILINEAR):
     if interpolation == NEAREST or not torch.is_floating_point(image):
         resized = F.interpolate(img.float(), size=(new_h, new_w), mode="nearest").to(image.dtype)
     else:
-        # torchvision's tensor resize antialiases bilinear down-scaling by default
-        resized = F.interpolate(img, size=(new_h, new_w), mode="bilinear", align_corners=False, antialias=True)
+        resized = F.interpolate(img, size=(new_h, new_w), mode="bilinear", align_corners=False, antialias=bool(antialias))
     resized = resized.squeeze(0)
     pad_w, pad_h = target_size - new_w, target_size - new_h
     pad_left, pad_top = pad_w // 2, pad_h // 2
@@ -84,7 +91,7 @@ def reverse_resize_and_padding(image, meta, interpolation="bilinear"):
     return out.squeeze(0)
 
 
-def process_batch_forward(batch_images, target_size=512, interpolation=BILINEAR, device=None):
+def process_batch_forward(batch_images, target_size=512, interpolation=BILINEAR, device=None, antialias=None):
     """utils.py:77-97.  With a CUDA `device` the batch is produced on it by the HIP kernel (float images stay
     float32, integer label maps come back int64); otherwise the host path."""
     if _is_cuda_device(device) or (len(batch_images) and isinstance(batch_images[0], torch.Tensor) and batch_images[0].is_cuda):
@@ -98,13 +105,13 @@ def process_batch_forward(batch_images, target_size=512, interpolation=BILINEAR,
         batch = torch.empty((len(imgs), imgs[0].shape[0], target_size, target_size),
                             dtype=torch.int64 if integer else torch.float32, device=dev)
         with torch.cuda.device(dev):
-            meta_list = [_resize_pad_into(im, batch[i], target_size, interpolation) for i, im in enumerate(imgs)]
+            meta_list = [_resize_pad_into(im, batch[i], target_size, interpolation, antialias) for i, im in enumerate(imgs)]
         return batch, meta_list
     resized_batch, meta_list = [], []
     for image in batch_images:
         if image.ndim == 3 and image.shape[0] == 4:
             image = image[:3, ...]
-        r, meta = resize_with_padding(image, target_size, interpolation)
+        r, meta = resize_with_padding(image, target_size, interpolation, antialias)
         resized_batch.append(r)
         meta_list.append(meta)
     return torch.stack(resized_batch), meta_list

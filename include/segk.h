@@ -187,7 +187,8 @@ int segk_vit_tokens_to_grid(const float* h, void* out, int B, int T, int D, int 
 /* ---- eval-time pre/post-processing on device (utils/utils.py:13-115; training.py:87-99) ---------------------------
  * one image [C,H,W] -> its slot [C,T,T] of the network batch: resize to (nh,nw) + zero padding (utils.py:13-49).
  * mode 0: anti-aliased bilinear = F.interpolate(bilinear, align_corners=False, antialias=True), what torchvision's
- * tensor TF.resize computes; mode 1: nearest.  elem 0: float32, 1: int64 (labels; mode 1 only). */
+ * tensor TF.resize computes from 0.17 on; mode 2: plain two-tap bilinear (antialias=False: torchvision < 0.17 on
+ * tensors; the reference pins no version); mode 1: nearest.  elem 0: float32, 1: int64 (labels; mode 1 only). */
 int segk_resize_pad(const void* img, void* out, int C, int H, int W, int nh, int nw, int T, int pad_top, int pad_left,
                     int mode, int elem, segk_stream_t s);
 /* slot [C,T,T] fp32 -> crop the (nh,nw) window at (pad_top,pad_left) -> [C,oh,ow]: F.interpolate bilinear

@@ -40,6 +40,19 @@ def test_forward_bilinear_antialiased(seg, T):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("T", [32, 64])
+def test_forward_bilinear_without_antialiasing(seg, T):
+    """antialias=False (torchvision < 0.17 on tensors): the plain two-tap bilinear mode of segk_resize_pad"""
+    from image_segmentation_amd.utils import process_batch_forward
+    imgs = [fill(s, 10 + i, 0, 1) for i, s in enumerate(SHAPES) if s[0] in (3, 4)]
+    ref, rmeta = resize_ref.process_batch_forward(imgs, T, antialias=False)
+    out, meta = process_batch_forward(imgs, target_size=T, device="cuda", antialias=False)
+    assert meta == rmeta
+    assert np.abs(cpu(out) - ref.numpy()).max() < 2e-6
+    aa, _ = process_batch_forward(imgs, target_size=T, device="cuda")
+    assert not torch.equal(aa, out)                      # the default (anti-aliased) differs on down-scaled images
+
+
 def test_forward_nearest_labels_exact(seg):
     from image_segmentation_amd.utils import process_batch_forward, NEAREST
     for dt in (torch.int64, torch.uint8, torch.float32):

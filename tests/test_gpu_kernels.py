@@ -127,6 +127,46 @@ def test_conv3x3_bf16_persistent_units(ops):
         assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2)
 
 
+def test_conv3x3_bf16_register_stationary(ops):
+    """conv_rs_kernel (Cin <= 64, 64-channel tiles, W > 16): many tiles per workgroup (the three-slot DMA ring wraps
+    several times), partial tiles on both edges, one and two channel tiles, two destinations (the concat data gradient
+    of an Up block), two 32-channel sources, statistics rows per wave -- against fp32 torch on the same bf16 inputs."""
+    from image_segmentation_amd import _lib
+    dtype = torch.bfloat16
+    cases = [(8, 64, 64, 256, 256, 0), (3, 64, 128, 72, 104, 0), (2, 32, 64, 50, 70, 0), (2, 64, 128, 40, 96, 64),
+             (1, 64, 64, 8, 32, 0)]
+    for B, Cin, Cout, H, W, split in cases:
+        x = fill((B, Cin, H, W), 31, -1, 1)
+        w = fill((Cout, Cin, 3, 3), 32, -1, 1) / np.sqrt(9 * Cin)
+        ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), padding=1)
+        xa = ops.to_act(dev(x), dtype); pa, CAp = ops.act_info(xa, dtype)
+        wp = ops.pack_conv(dev(w), Cin, 0, dtype, 0)
+        tiles = _lib.query("segk_conv_tiles", B, H, W, CAp, Cout, 1)
+        st = torch.full((_lib.query("segk_bn_stats_floats", tiles, Cout),), 7.0, dtype=torch.float32, device="cuda")
+        if split:
+            o1 = torch.empty((B, H, W, split), dtype=dtype, device="cuda")
+            o2 = torch.empty((B, H, W, Cout - split), dtype=dtype, device="cuda")
+            ops.conv3x3(xa, pa, CAp, 0, 0, wp, o1.data_ptr(), split, o2.data_ptr(), Cout - split, B, H, W, dtype, stats=st)
+            y = torch.cat([back(ops.act_view(o1, split)), back(ops.act_view(o2, Cout - split))], 1)
+        else:
+            out = torch.empty((B, H, W, Cout), dtype=dtype, device="cuda")
+            ops.conv3x3(xa, pa, CAp, 0, 0, wp, out.data_ptr(), Cout, 0, 0, B, H, W, dtype, stats=st)
+            y = back(ops.act_view(out, Cout))
+        torch.cuda.synchronize()
+        assert (y - ref).abs().max().item() < tol(dtype, 1) * 1.5, (B, Cin, Cout, H, W)
+        sums = st[:tiles * Cout * 2].view(tiles, Cout, 2).cpu().sum(0)
+        refq = y                                   # statistics are taken from the fp32 accumulators: compare loosely
+        assert torch.allclose(sums[:, 0], ref.sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2 * B * H * W * 0.05), (B, Cin, Cout, H, W)
+        assert torch.allclose(sums[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2), (B, Cin, Cout, H, W)
+    # two 32-channel sources == conv of the concatenation
+    B, H, W = 2, 24, 64
+    xa_ = fill((B, 32, H, W), 41, -1, 1); xb_ = fill((B, 32, H, W), 42, -1, 1)
+    w2 = fill((64, 64, 3, 3), 43, -1, 1) / 24
+    ref = F.conv2d(torch.cat([xa_, xb_], 1).to(dtype).float(), w2.to(dtype).float(), padding=1)
+    y = _conv_direct(ops, xa_, w2, dtype, xb=xb_)
+    assert (y - ref).abs().max().item() < tol(dtype, 1) * 1.5
+
+
 @pytest.mark.parametrize("C", [64, 128])
 def test_conv3x3_bf16_prologue_side_output(ops, C):
     """segk_conv3x3_act (second conv of a block): conv(relu(z*scale+shift)) plus the hidden activation itself as a

@@ -185,6 +185,10 @@ def test_resize_geometry_and_host_path_match_oracle():
     out, meta = process_batch_forward(imgs, target_size=64)
     ref, rmeta = resize_ref.process_batch_forward(imgs, 64)
     assert meta == rmeta and torch.equal(out, ref)
+    # torchvision < 0.17 did not anti-alias tensor resizes: the switch reaches the host path too
+    out2, _ = process_batch_forward(imgs, target_size=64, antialias=False)
+    ref2, _ = resize_ref.process_batch_forward(imgs, 64, antialias=False)
+    assert torch.equal(out2, ref2) and not torch.equal(out2, out)
     labs = [labels((1, 37, 53), 1, 4), labels((1, 20, 30), 2, 4)]
     lo, _ = process_batch_forward(labs, target_size=48, interpolation=NEAREST)
     lr, _ = resize_ref.process_batch_forward(labs, 48, nearest=True)

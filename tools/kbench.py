@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--pro", action="store_true")
     ap.add_argument("--lib", type=str, default="")
+    ap.add_argument("--stamps", action="store_true", help="with the stamp build (tools/stamp_build.sh): print the conv_rs "
+                    "kernel's per-phase cycle shares (read from the statistics buffer the diagnostic build overwrites)")
     args = ap.parse_args()
     dt = torch.bfloat16
     B = 32
@@ -58,6 +60,17 @@ def main():
             us = timeit(lambda: ops.conv3x3(x, x.data_ptr(), cin, 0, 0, wp, out.data_ptr(), cout, 0, 0, B, hw, hw, dt,
                                             scale=sc, shift=sh, stats=st), args.iters)
             print(f"conv  {name:26s} {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {by/us/1e3:7.1f} GB/s(alg)")
+            if args.stamps:
+                torch.cuda.synchronize()
+                n = min(st.numel() // 2, 256 * 8 * 8)
+                t = st[:2 * n].view(torch.int64).view(-1, 8, 8).double().cpu()       # [workgroup][wave][8]
+                tot = t[:, :, 6].clamp(min=1)
+                names = ["barrier wait", "MFMA loop", "DMA issue", "wait next tile", "epilogue", "loop tail/transform"]
+                print(f"      stamps over {t.shape[0]} workgroups: kernel {tot.mean():.0f} cycles per wave (min {tot.min():.0f} max {tot.max():.0f})")
+                for i, nm in enumerate(names):
+                    sh = (t[:, :, i] / tot)
+                    print(f"        {nm:22s} {100*sh.mean():5.1f} %   waves0-3 {100*sh[:, :4].mean():5.1f} %  waves4-7 {100*sh[:, 4:].mean():5.1f} %   "
+                          f"({t[:, :, i].mean():.0f} cycles)")
         if args.what in ("wgrad", "all"):
             def f():
                 ops.wgrad(g.data_ptr(), cout, x.data_ptr(), cin, 0, 0, B, hw, hw, 0, dt, "cuda", scale=sc, shift=sh)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Diagnostic library with in-kernel phase stamps (never shipped): tools/ubench/bin/libsegk_stamp.so
+# usage: tools/stamp_build.sh   then   python tools/kbench.py conv --only 64->64 --lib tools/ubench/bin/libsegk_stamp.so --stamps
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+C=$R/image_segmentation_amd/csrc
+mkdir -p $R/tools/ubench/bin/stamp_obj
+for f in api conv_igemm conv_rs wgrad bn_pool pack head_loss resize vit gemm; do
+  if [ "$f" = conv_rs ]; then X="-DSEGK_RS_STAMPS"; else X=""; fi
+  if [ "$f" = conv_rs ] || [ ! -f $C/$f.o ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off $X -c $C/$f.hip -o $R/tools/ubench/bin/stamp_obj/$f.o
+  else
+    cp $C/$f.o $R/tools/ubench/bin/stamp_obj/$f.o
+  fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/ubench/bin/libsegk_stamp.so $R/tools/ubench/bin/stamp_obj/*.o
+echo built $R/tools/ubench/bin/libsegk_stamp.so
