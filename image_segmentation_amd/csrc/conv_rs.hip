@@ -111,6 +111,10 @@ __device__ __forceinline__ uint4 pack8_bf16(const float (&v)[8]) {
   return o;
 }
 
+#ifndef RS_ABL
+#define RS_ABL 0      // diagnostic builds: bit 0 = no output stores, bit 1 = no DMA, bit 2 = no MFMA loop (timing only)
+#endif
+
 template <int NCH, bool PRO>
 __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
   typedef bf16_t T;
@@ -118,8 +122,7 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
   constexpr int NPIECE = NCH * RS_NBLK;              // DMA pieces (1 KiB) per tile
   constexpr int NPW = (NPIECE + 7) / 8;              // per wave: waves below NPIECE % 8 move NPW pieces, the others NPW - 1
   constexpr int NFULL = NPIECE % 8 == 0 ? 8 : NPIECE % 8;
-  constexpr int STATS_OFF = 3 * TILEB;               // 8 waves x [32 lane pairs][8 sums | 8 sums of squares]
-  constexpr int TAB_OFF = STATS_OFF + 8 * 2048;      // PRO: [NCH][4 pieces][8 scale | 8 shift]
+  constexpr int TAB_OFF = 3 * TILEB;                 // PRO: [NCH][4 pieces][8 scale | 8 shift]
   constexpr int NSTEP = NCH * 9;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -139,11 +142,12 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
   const int mt_end = min(MT, (xcd + 1) * mpx);
   const int n0 = nt * 64;
   const int srow = (xcd * GW + slot) * 4 + s;         // this wave's row of the statistics partials
-  // lane (g, i = lane & 15) finishes the wave's statistics: i < 8 the sum, i >= 8 the sum of squares of channel 8 g + (i & 7)
-  float* const stat_dst = a.stats ? a.stats + ((size_t)srow * a.Ntot + n0 + 32 * jh + 8 * g + (col & 7)) * 2 + (col >> 3)
-                                  : nullptr;
+  float2* const stat_dst = a.stats ? (float2*)a.stats + (size_t)srow * a.Ntot + n0 + 32 * jh + 8 * g : nullptr;
   if (mt >= mt_end) {                                 // nothing to do: the partial rows still have to exist
-    if (stat_dst) *stat_dst = 0.f;
+    if (stat_dst && col == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) stat_dst[i] = make_float2(0.f, 0.f);
+    }
     return;
   }
   auto decode = [&](int m, int& b, int& y0, int& x0) {
@@ -169,8 +173,6 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
       }
 
   // ---- LDS bookkeeping
-#pragma unroll
-  for (int i = 0; i < 8; ++i) *(float*)(smem + STATS_OFF + wave * 2048 + (i * 64 + lane) * 4) = 0.f;
   if (PRO) {
     if (tid < NCH * 32) {
       const int c = tid >> 5, r = tid & 31, q = r >> 3, i = r & 7;
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
       unsigned po = poff[i];
       asm volatile("" : "+v"(po));                    // keeps hipcc from hoisting 64-bit (base + offset) sums out of the
                                                       // tile loop (five register pairs, spilled around the MFMA loop)
+      if (RS_ABL & 2) continue;
       if (interior) {
         __builtin_amdgcn_global_load_lds((glb_vp)(cb + po), (lds_vp)dst, 16, 0, 0);
       } else {
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
 
   // ---- prologue: tiles 0 and 1 in flight, tile 0 landed (and transformed)
   int m1 = mt + GW, m2 = mt + 2 * GW;                 // the next two tiles of this workgroup
+  const bool class_b = wave >= 4;
   issue_tile(mt, 0);
   if (m1 < mt_end) {
     issue_tile(m1, 1);
@@ -344,125 +348,53 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
   }
   int bsel = 0;                                       // ring slot of the current tile
   const bool has_stats = (a.stats != nullptr);
-  const int stat_acc = STATS_OFF + wave * 2048 + (lane >> 1) * 64;     // the lane pair's 16 accumulators in LDS
 
 #ifdef SEGK_RS_STAMPS
   unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
   const unsigned long long stamp_t0 = stamp_last;
 #endif
-  // ---- the two waves of a SIMD run the tile's phases in opposite order (waves w and w + 4 share a SIMD).  Class A
-  // (waves 0-3): multiply tile t, refill the DMA ring, store tile t.  Class B (waves 4-7): store tile t-1 (its
-  // accumulators simply stay in registers across the barrier), refill the ring, multiply tile t.  One wave's MFMA
-  // stream then runs beside its partner's vector-memory issue and VALU work instead of both waves queueing for the
-  // matrix pipe first and for the memory pipe afterwards (measured: the symmetric order left the older waves waiting at
-  // the barrier for a quarter of the kernel).
-  const bool class_b = wave >= 4;
-  f32x4 acc[2][4];
-  int pb = 0, py0 = 0, px0 = 0;                      // class B: the tile whose results are still in `acc`
+  // ---- a tile is multiplied in two passes (its slab's two tile rows), 16 accumulator registers each: the registers
+  // this frees hold the wave's BatchNorm statistics for the WHOLE kernel (per lane: 8 channels x (sum, sum of squares)),
+  // so a pass's epilogue is a pack, two stores and 32 accumulating VALU operations -- no cross-lane step, no LDS (an
+  // earlier form reduced over lanes and accumulated in LDS per tile: a quarter of the kernel's time).
+  //
+  // The two waves of a SIMD (w and w + 4) run the phases of a tile in different orders, so that one wave's MFMA stream
+  // runs beside its partner's vector-memory issue and VALU work instead of both queueing for the matrix pipe first and
+  // for the memory pipe afterwards (the older wave wins the pipe, finishes its passes first and would then idle at the
+  // barrier):   class A (waves 0-3):  barrier | pass 0, store | pass 1, store | refill the DMA ring | wait
+  //             class B (waves 4-7):  barrier | store pass 1 of the PREVIOUS tile (its 16 accumulators simply stay in
+  //                                   registers across the barrier) | refill the ring | pass 0, store | pass 1 | wait
+  float s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  f32x4 acc1[2][2];                                   // pass 1 (class B: kept across the barrier)
+  int pb = 0, py0 = 0, px0 = 0;
   bool have_prev = false;
 
-  auto epilogue = [&](int ub, int uy0, int ux0) {
-    // lane (col, g) holds channels 8 g .. 8 g + 7 of its half for pixel col of each 16-pixel group
-    char* const tb = (char*)(dch + ((size_t)(ub * H + uy0) * W + ux0) * dstride);    // wave-uniform
-    float s1[8], s2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    if ((uy0 + 8 <= H) && (ux0 + 32 <= W)) {          // the common case: the whole tile lies inside the image
-#pragma unroll
-      for (int pg = 0; pg < 4; ++pg) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = acc[0][pg][i]; v[4 + i] = acc[1][pg][i]; }
-        if (has_stats) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] = fmaf(v[i], v[i], s2[i]); }
-        }
-        *(uint4*)(tb + ((pg & 1) * xstep + (pg >> 1) * ystep) + soff) = pack8_bf16(v);
-      }
-    } else {
-#pragma unroll
-      for (int pg = 0; pg < 4; ++pg) {
-        const int y = uy0 + 2 * s + (pg >> 1), x = ux0 + 16 * (pg & 1) + col;
-        const bool in = (y < H) && (x < W);           // pixels past the image edge: not stored, not in the statistics
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = in ? acc[0][pg][i] : 0.f; v[4 + i] = in ? acc[1][pg][i] : 0.f; }
-        if (has_stats) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] = fmaf(v[i], v[i], s2[i]); }
-        }
-        if (in) *(uint4*)(tb + ((pg & 1) * xstep + (pg >> 1) * ystep) + soff) = pack8_bf16(v);
-      }
-    }
-    if (has_stats) {
-      // pairs of pixel lanes are summed with one DPP add; the even lane adds the pair's 16 values to its accumulators in
-      // LDS (wave-private read-modify-write; the reads go through inline asm like every LDS read inside the loop; LDS
-      // float atomics were measured an order of magnitude slower).  The rest of the reduction runs once, after the
-      // last tile.
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { s1[i] = dpp_add<0xB1>(s1[i]); s2[i] = dpp_add<0xB1>(s2[i]); }
-      if ((lane & 1) == 0) {
-        uint4 q0, q1, q2, q3;
-        lds_rd128<0>(q0, stat_acc);
-        lds_rd128<16>(q1, stat_acc);
-        lds_rd128<32>(q2, stat_acc);
-        lds_rd128<48>(q3, stat_acc);
-        lds_wait<0>();
-        __builtin_amdgcn_sched_barrier(0);
-        q0.x = __float_as_uint(__uint_as_float(q0.x) + s1[0]); q0.y = __float_as_uint(__uint_as_float(q0.y) + s1[1]);
-        q0.z = __float_as_uint(__uint_as_float(q0.z) + s1[2]); q0.w = __float_as_uint(__uint_as_float(q0.w) + s1[3]);
-        q1.x = __float_as_uint(__uint_as_float(q1.x) + s1[4]); q1.y = __float_as_uint(__uint_as_float(q1.y) + s1[5]);
-        q1.z = __float_as_uint(__uint_as_float(q1.z) + s1[6]); q1.w = __float_as_uint(__uint_as_float(q1.w) + s1[7]);
-        q2.x = __float_as_uint(__uint_as_float(q2.x) + s2[0]); q2.y = __float_as_uint(__uint_as_float(q2.y) + s2[1]);
-        q2.z = __float_as_uint(__uint_as_float(q2.z) + s2[2]); q2.w = __float_as_uint(__uint_as_float(q2.w) + s2[3]);
-        q3.x = __float_as_uint(__uint_as_float(q3.x) + s2[4]); q3.y = __float_as_uint(__uint_as_float(q3.y) + s2[5]);
-        q3.z = __float_as_uint(__uint_as_float(q3.z) + s2[6]); q3.w = __float_as_uint(__uint_as_float(q3.w) + s2[7]);
-        lds_wr128<0>(stat_acc, q0);
-        lds_wr128<16>(stat_acc, q1);
-        lds_wr128<32>(stat_acc, q2);
-        lds_wr128<48>(stat_acc, q3);
-      }
-    }
-  };
-
-  for (;;) {
-    int ub, uy0, ux0;
-    decode(mt, ub, uy0, ux0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own LDS writes (transform, statistics) are done
-    RS_STAMP(5);                                      // (loop bookkeeping / transform of the previous iteration)
-    __builtin_amdgcn_s_barrier();                     // the tile is complete in LDS for every wave
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    RS_STAMP(0);                                      // barrier wait
-    // the ring slot two tiles back is free now (every wave passed this tile's barrier)
-    const int bnext = (bsel == 2) ? 0 : bsel + 1, bfree = (bnext == 2) ? 0 : bnext + 1;
-
-    if (class_b) {
-      if (have_prev) epilogue(pb, py0, px0);
-      RS_STAMP(4);                                    // epilogue
-      if (m2 < mt_end) issue_tile(m2, bfree);
-      RS_STAMP(2);                                    // DMA issue
-    }
-
+  auto run_pass = [&](auto HC, f32x4 (&acc)[2][2]) {
+    constexpr int h = decltype(HC)::value;            // tile row 2 s + h of the slab
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int pg = 0; pg < 4; ++pg) acc[cb][pg] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // fragment f = 4 * step + pixel group lives in ring register f % RING and is fetched RING - 1 fragments (128 MFMA
-    // cycles) ahead of its two MFMAs, into the register the fragment consumed just before has left
-    constexpr int RING = 4;
+      for (int pg = 0; pg < 2; ++pg) acc[cb][pg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragment f = 2 * step + half row lives in ring register f % RING and is fetched RING - 1 fragments ahead of its
+    // two MFMAs, into the register the fragment consumed just before has left
+#ifndef RS_RING
+#define RS_RING 5
+#endif
+    constexpr int RING = RS_RING;
     uint4 fr[RING];
     auto rd = [&](auto FC) {
-      constexpr int f = decltype(FC)::value, ct = f >> 2, pg = f & 3;
+      constexpr int f = decltype(FC)::value, ct = f >> 1, pg = f & 1;
       constexpr int c = ct / 9, t = ct - c * 9, dy = t / 3, dx = t - dy * 3;
-      constexpr int c0 = RS_PW * ((pg >> 1) + dy) + 16 * (pg & 1) + dx;
+      constexpr int c0 = RS_PW * (h + dy) + 16 * pg + dx;
       lds_rd128<(c0 >> 3) * 512 + c * RS_CHB>(fr[f % RING], abuf[c0 & 7]);
     };
-    constexpr int NFRAG = 4 * NSTEP;
-    static_for<0, RING - 1>(rd);
-    static_for<0, NFRAG>([&](auto FC) {
-      constexpr int f = decltype(FC)::value, ct = f >> 2, pg = f & 3;
+    constexpr int NFRAG = 2 * NSTEP;
+    if (!(RS_ABL & 4)) static_for<0, RING - 1>(rd);
+    if (!(RS_ABL & 4)) static_for<0, NFRAG>([&](auto FC) {
+      constexpr int f = decltype(FC)::value, ct = f >> 1, pg = f & 1;
       lds_wait<(NFRAG - 1 - f < RING - 2) ? NFRAG - 1 - f : RING - 2>();   // fragment f has arrived (LDS returns in order)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -473,24 +405,80 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
       if constexpr (f + RING - 1 < NFRAG) rd(std::integral_constant<int, f + RING - 1>{});
     });
     __builtin_amdgcn_sched_barrier(0);
-    RS_STAMP(1);                                      // MFMA loop
+  };
+  // epilogue of a pass, from registers: lane (col, g) holds channels 8 g .. 8 g + 7 of its half for pixel
+  // (2 s + h, 16 pg + col) of tile (ub, uy0, ux0)
+  auto store_pass = [&](auto HC, const f32x4 (&acc)[2][2], int ub, int uy0, int ux0) {
+    constexpr int h = decltype(HC)::value;
+    char* const tb = (char*)(dch + ((size_t)(ub * H + uy0) * W + ux0) * dstride);    // wave-uniform
+    const bool full = (uy0 + 8 <= H) && (ux0 + 32 <= W);
+#pragma unroll
+    for (int pg = 0; pg < 2; ++pg) {
+      float v[8];
+      bool in = true;
+      if (!full) {                                    // pixels past the image edge: not stored, not in the statistics
+        in = (uy0 + 2 * s + h < H) && (ux0 + 16 * pg + col < W);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = in ? acc[0][pg][i] : 0.f; v[4 + i] = in ? acc[1][pg][i] : 0.f; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = acc[0][pg][i]; v[4 + i] = acc[1][pg][i]; }
+      }
+      if (has_stats) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] = fmaf(v[i], v[i], s2[i]); }
+      }
+      if (!(RS_ABL & 1)) {
+        if (in) *(uint4*)(tb + (pg * xstep + h * ystep) + soff) = pack8_bf16(v);
+      } else {
+        asm volatile("" ::"v"(v[0] + v[7]));
+      }
+    }
+  };
+  const std::integral_constant<int, 0> H0{};
+  const std::integral_constant<int, 1> H1{};
 
-    // ---- make sure the NEXT tile's own pieces have landed: only the pieces of the tile after it, issued in this
-    // iteration, may stay in flight (every older operation, stores included, is at least one MFMA loop old)
-    if (!class_b) {
+  for (;;) {
+    int ub, uy0, ux0;
+    decode(mt, ub, uy0, ux0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own LDS writes (transform) are done
+    RS_STAMP(5);                                      // (loop bookkeeping / transform of the previous iteration)
+    __builtin_amdgcn_s_barrier();                     // the tile is complete in LDS for every wave
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    RS_STAMP(0);                                      // barrier wait
+    // the ring slot two tiles back is free now (every wave passed this tile's barrier)
+    const int bnext = (bsel == 2) ? 0 : bsel + 1, bfree = (bnext == 2) ? 0 : bnext + 1;
+    if (class_b) {
+      if (have_prev) store_pass(H1, acc1, pb, py0, px0);
+      RS_STAMP(4);                                    // epilogue
       if (m2 < mt_end) issue_tile(m2, bfree);
       RS_STAMP(2);                                    // DMA issue
     }
-    if (m2 < mt_end) wait_pieces();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    RS_STAMP(3);                                      // wait for the next tile's pieces
+    {
+      f32x4 acc0[2][2];
+      run_pass(H0, acc0);
+      RS_STAMP(1);                                    // MFMA pass
+      store_pass(H0, acc0, ub, uy0, ux0);
+      RS_STAMP(4);
+    }
+    run_pass(H1, acc1);
+    RS_STAMP(1);
     if (!class_b) {
-      epilogue(ub, uy0, ux0);
-      RS_STAMP(4);                                    // epilogue
+      store_pass(H1, acc1, ub, uy0, ux0);
+      RS_STAMP(4);
+      if (m2 < mt_end) issue_tile(m2, bfree);
+      RS_STAMP(2);
     } else {
       pb = ub; py0 = uy0; px0 = ux0;
       have_prev = true;
     }
+    // ---- the NEXT tile's own pieces have landed: only the pieces of the tile after it may stay in flight (class B
+    // issued those before its passes: the two stores of pass 0 are younger, so it also waits for the first two of them,
+    // which are a whole tile old by now)
+    if (m2 < mt_end) wait_pieces();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RS_STAMP(3);                                      // wait for the next tile's pieces
 
     if (m1 >= mt_end) break;
     if (PRO) transform_tile(m1, bnext);
@@ -499,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
     for (int k = 0; k < 8; ++k) abuf[k] += (bnext == 0) ? -2 * TILEB : TILEB;
     bsel = bnext;
   }
-  if (class_b && have_prev) epilogue(pb, py0, px0);   // the last tile of the deferred class
+  if (class_b && have_prev) store_pass(H1, acc1, pb, py0, px0);   // the deferred pass of the last tile
 
 #ifdef SEGK_RS_STAMPS
   if (has_stats && lane == 0) {                       // [workgroup][wave][8]: six phase sums, total, unused
@@ -511,20 +499,22 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
   }
   return;
 #endif
-  if (has_stats) {
-    // lane (g, i): value i (8 sums | 8 sums of squares) of lane row g, summed over the row's 8 lane pairs, fixed order
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const float* acc_l = (const float*)(smem + STATS_OFF + wave * 2048 + g * 8 * 64 + col * 4);
-    float t = 0.f;
+  if (has_stats) {                                    // once per kernel: sum over the 16 pixel lanes of each lane row
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += acc_l[k * 16];
-    *stat_dst = t;
+    for (int i = 0; i < 8; ++i) {
+      s1[i] = row16_sum(s1[i]);
+      s2[i] = row16_sum(s2[i]);
+    }
+    if (col == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) stat_dst[i] = make_float2(s1[i], s2[i]);
+    }
   }
 }
 
 template <int NCH, bool PRO>
 int launch_rs(ConvArgs a, hipStream_t st) {
-  constexpr size_t lds = 3 * (size_t)NCH * RS_CHB + 8 * 2048 + NCH * 256;
+  constexpr size_t lds = 3 * (size_t)NCH * RS_CHB + NCH * 256;
   static_assert(lds <= 160 * 1024, "conv_rs: LDS exceeds 160 KiB");
   a.tiles_x = cdiv(a.W, 32);
   a.tiles_y = cdiv(a.H, 8);

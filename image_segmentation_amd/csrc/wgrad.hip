@@ -15,11 +15,20 @@
 // fp32: exact 32x32x2 MFMA, one ds_read_b32 per operand (lanes = 32 contiguous channels).
 // Each wave owns a 32x32 (n,k) block for ALL taps (9 accumulators); split-K over spatial tiles writes
 // fp32 slabs that segk_wgrad_reduce sums in fixed order (bit-stable, no atomics).
+#include <type_traits>
 #include "common.hpp"
 #include "segk_internal.h"
 #include "../../include/segk.h"
 
 namespace {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (inline-asm immediates need constants)
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 template <typename T, int GEO> struct WG {
   static constexpr bool BF = (sizeof(T) == 2);
@@ -175,10 +184,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
         const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
         const int gsub = g & 1, h = g >> 1;
         const int coff = (16 * gsub + 4 * p) * 2;
-        typedef __attribute__((address_space(3))) s16x4* lds_v4;
-#pragma unroll
+      #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int xa = 8 * h + q;   // pixel column of read 0; read 1 is +4
+          typedef __attribute__((address_space(3))) s16x4* lds_v4;
           const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(dzb + (r * 16 + xa) * BLKP + coff));
           const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(dzb + (r * 16 + xa + 4) * BLKP + coff));
           const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -246,7 +255,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   constexpr int UB = WU * NU * BLKP, VB = WV * NV * BLKP, BUF = UB + VB;
   constexpr int NINSTR = WU * 8 + WV * 12;                // 1 KiB DMA wave-instructions per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((address_space(3))) s16x4* lds_v4;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -321,12 +329,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     psc = a.scale[c];
     psh = a.shift[c];
   }
-  auto frag = [&](const char* base, int pix) {
-    const s16x4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + pix * BLKP + coff));
-    const s16x4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + (pix + 4) * BLKP + coff));
-    return __builtin_shufflevector(f0, f1, 0, 1, 2, 3, 4, 5, 6, 7);
-  };
+  // Fragment reads go through inline asm: hipcc orders every LDS load it can see behind ALL pending LDS-DMA (an
+  // s_waitcnt vmcnt(0) in front of the tile's first read), which drained the next tile's DMA before the MFMAs it was
+  // meant to fly under.  The destination is valid only after the counted lgkmcnt wait placed by the loop below (LDS
+  // returns in order), and nothing is scheduled across those waits (sched_barrier).
   typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto frag_rd = [&](s16x8& dst, int vaddr, auto OFFc) {      // vaddr: lane part + tile buffer base; OFF: pixel offset
+    constexpr int OFF = decltype(OFFc)::value;
+    s16x4 f0, f1;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f0) : "v"(vaddr), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f1) : "v"(vaddr), "n"(OFF + 4 * BLKP));
+    dst = __builtin_shufflevector(f0, f1, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
   // BatchNorm(scale, shift) + ReLU on the 8 pixels of one channel; vmask bit j = pixel j lies inside the image.
   // Instruction count matters here (VALU issued beside the MFMAs): scalar fp32 fma (packed fp32 is slower next to
   // MFMAs), one bf16 conversion per pair, the ReLU as a packed signed-16-bit max on the bf16 bit patterns
@@ -360,8 +374,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   for (; t < ntiles; t += a.S) {
     if (t + a.S < ntiles) issue_tile(t + a.S, cur ^ 1);    // DMA of the next tile flies under the MFMAs
     if (computes) {
-      const char* const ub = smem + cur * BUF + wu * (NU * BLKP);
-      const char* const vb = smem + cur * BUF + UB + wv * (NV * BLKP);
       unsigned xmask = 0xffu, rows_ok = R;
       if (PRO) {                                           // partial tiles: mask pixels outside the image
         const int bimg = t / (tiles_y * tiles_x);
@@ -373,34 +385,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
         for (int j = 0; j < 8; ++j)   // fragment element j = pixel column 8h + j of the tile row (two 4-row blocks)
           xmask |= (x0 + 8 * h + j < W ? 1u : 0u) << j;
       }
+      // Read schedule of a tile (transposing reads, two per fragment): the three kx-fragments of patch rows 0..2 and
+      // the dz row 0 up front; then per dz row r: [dz row r+1] -> 3 MFMAs (ky = 0) -> [patch row r+3, into the
+      // registers row r has just left] -> 6 MFMAs (ky = 1, 2).  Reads retire in order, so "all but the N youngest
+      // reads" (s_waitcnt lgkmcnt(N)) names exactly what has arrived.
+      const int ua = cur * BUF + wu * (NU * BLKP) + xa * BLKP + coff;
+      const int va = cur * BUF + UB + wv * (NV * BLKP) + xa * BLKP + coff;
       s16x8 fv[3][3], fu[2];
-#pragma unroll
-      for (int y = 0; y < 3; ++y)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) fv[y][kx] = frag(vb, y * 18 + xa + kx);
-      fu[0] = frag(ub, xa);
+      static_for<0, 9>([&](auto IC) {
+        constexpr int y = decltype(IC)::value / 3, kx = decltype(IC)::value % 3;
+        frag_rd(fv[y][kx], va, std::integral_constant<int, (y * 18 + kx) * BLKP>{});
+      });
+      frag_rd(fu[0], ua, std::integral_constant<int, 0>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       if (PRO) fu[0] = transform(fu[0], rows_ok > 0 ? xmask : 0u);
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (r + 1 < R) {
-          fu[(r + 1) & 1] = frag(ub, (r + 1) * 16 + xa);
-          if (PRO) fu[(r + 1) & 1] = transform(fu[(r + 1) & 1], (unsigned)(r + 1) < rows_ok ? xmask : 0u);
-        }
+      static_for<0, R>([&](auto RC) {
+        constexpr int r = decltype(RC)::value;
+        if constexpr (r + 1 < R) frag_rd(fu[(r + 1) & 1], ua, std::integral_constant<int, (r + 1) * 16 * BLKP>{});
+        // dz row r and patch row r are in registers: younger are patch row r+2 (6 reads, r > 0) and dz row r+1 (2)
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((r == 0 ? 0 : 6) + (r + 1 < R ? 2 : 0)) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 fur = __builtin_bit_cast(bf16x8, fu[r & 1]);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {                   // ky = 0 consumes patch row r ...
           const bf16x8 fvr = __builtin_bit_cast(bf16x8, fv[r % 3][kx]);
-          constexpr int dummy = 0; (void)dummy;
           const int ti = PRO ? 8 - kx : kx;
           acc[ti] = PRO ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fvr, fur, acc[ti], 0, 0, 0)
                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fur, fvr, acc[ti], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (r + 1 < R) {                                   // ... whose register slot then takes patch row r+3
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) fv[r % 3][kx] = frag(vb, (r + 3) * 18 + xa + kx);
+        if constexpr (r + 1 < R) {                         // ... whose register slot then takes patch row r+3
+          static_for<0, 3>([&](auto KC) {
+            constexpr int kx = decltype(KC)::value;
+            frag_rd(fv[r % 3][kx], va, std::integral_constant<int, ((r + 3) * 18 + kx) * BLKP>{});
+          });
         }
+        // patch rows r+1 and r+2 are in registers: younger are dz row r+1 (2) and patch row r+3 (6)
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(r + 1 < R ? 8 : 0) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ky = 1; ky < 3; ++ky)
@@ -412,7 +434,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fur, fvr, acc[ti], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
-      }
+        if constexpr (PRO && r + 1 < R) {                  // the next dz row has arrived (only patch row r+3 is younger)
+          asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          fu[(r + 1) & 1] = transform(fu[(r + 1) & 1], (unsigned)(r + 1) < rows_ok ? xmask : 0u);
+        }
+      });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile's DMA has landed
     __syncthreads();

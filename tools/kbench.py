@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--pro", action="store_true")
+    ap.add_argument("--no-stats", action="store_true", help="conv without the BatchNorm statistics epilogue")
     ap.add_argument("--lib", type=str, default="")
     ap.add_argument("--stamps", action="store_true", help="with the stamp build (tools/stamp_build.sh): print the conv_rs "
                     "kernel's per-phase cycle shares (read from the statistics buffer the diagnostic build overwrites)")
@@ -58,7 +59,7 @@ def main():
             tiles = _lib.query("segk_conv_tiles", B, hw, hw, cin, cout, 1)
             st = torch.empty((_lib.query("segk_bn_stats_floats", tiles, cout),), dtype=torch.float32, device="cuda")
             us = timeit(lambda: ops.conv3x3(x, x.data_ptr(), cin, 0, 0, wp, out.data_ptr(), cout, 0, 0, B, hw, hw, dt,
-                                            scale=sc, shift=sh, stats=st), args.iters)
+                                            scale=sc, shift=sh, stats=None if args.no_stats else st), args.iters)
             print(f"conv  {name:26s} {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {by/us/1e3:7.1f} GB/s(alg)")
             if args.stamps:
                 torch.cuda.synchronize()

@@ -6,12 +6,13 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/image_segmentation_amd/csrc
 mkdir -p $R/tools/ubench/bin/stamp_obj
 for f in api conv_igemm conv_rs wgrad bn_pool pack head_loss resize vit gemm; do
-  if [ "$f" = conv_rs ]; then X="-DSEGK_RS_STAMPS"; else X=""; fi
+  if [ "$f" = conv_rs ]; then X="-DSEGK_RS_STAMPS ${RS_ABL:+-DRS_ABL=$RS_ABL} ${RS_EXTRA}"; else X=""; fi
   if [ "$f" = conv_rs ] || [ ! -f $C/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off $X -c $C/$f.hip -o $R/tools/ubench/bin/stamp_obj/$f.o
   else
     cp $C/$f.o $R/tools/ubench/bin/stamp_obj/$f.o
   fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/ubench/bin/libsegk_stamp.so $R/tools/ubench/bin/stamp_obj/*.o
-echo built $R/tools/ubench/bin/libsegk_stamp.so
+OUT=$R/tools/ubench/bin/libsegk_stamp${RS_ABL:+_abl$RS_ABL}${RS_TAG}.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $R/tools/ubench/bin/stamp_obj/*.o
+echo built $OUT
