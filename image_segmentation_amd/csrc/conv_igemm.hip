@@ -437,19 +437,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 //     step ahead.  Their waits (vmcnt, LDS-store queueing) no longer sit in any MFMA stream.
 // One s_barrier per step joins the two roles.  The weight ring keeps running across work units (the epilogue
 // tile overlays only [P0 | P1 | W2], dead at that point).  LDS: [W0 | W1 | P0 | P1 | W2], 80-byte pitch.
-template <int TWL, bool PRO, int BN>
+// M16: the consumers multiply with v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (the same LDS bytes and matrix cycles per
+// FLOP; on random data the chip holds a ~12 % higher clock on the 16x16 shape: tools/ubench/mfma_tiles.hip 1.79 vs
+// 1.60 PFLOP/s at this wave tile).  A 16x16x32 operand is 16 rows x one whole 64-byte chunk, so the LDS image changes:
+// patch pixels at a 96-byte pitch (conflict-free for 16 consecutive pixels at any tap shift), weight rows unpadded with
+// the 16-byte piece index XOR-ed by [0,3,2,1][(row >> 2) & 3] (conflict-free, rows never shift).
+template <int TWL, bool PRO, int BN, bool M16>
 __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) {
   using T = bf16_t;
   using E = ET<T>;
+  constexpr int PPIX = M16 ? 96 : PIXB;            // LDS pitch of a patch pixel's chunk
+  constexpr int WPIX = M16 ? 64 : PIXB;            // LDS pitch of a weight row
   // workgroup tile 256 px x 128 ch (consumers 2 x 2) or, for 64-channel layers, 512 px x 64 ch (consumers 4 x 1):
   // the same bytes per step and the same 128 x 64 consumer tile either way
   static_assert(BN == 128 || BN == 64, "channel tile is 128 or 64");
   constexpr int BM = 32768 / BN, NTHR = 512, NPT = 256;       // NPT: producer threads
   constexpr int WN = BN / 64, WM = 4 / WN, MF = 4, NF = 2;    // consumer waves: WM x WN, 128 px x 64 ch each
   constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
-  constexpr int ROWP = (PW * PIXB + 255) & ~255;
+  constexpr int ROWP = (PW * PPIX + 255) & ~255;
   constexpr int PB = PH * ROWP;                    // one patch chunk
-  constexpr int WB = 3 * BN * PIXB;                // one step of weights: 3 taps x 128 rows
+  constexpr int WB = 3 * BN * WPIX;                // one step of weights: 3 taps x 128 rows
   constexpr int NP = PH * PW * 4, NPL = (NP + NPT - 1) / NPT;
   constexpr int NWL = 3 * BN * 4 / NPT;            // 16-byte weight pieces per producer thread and step
   constexpr int POFF = 2 * WB, W2OFF = POFF + 2 * PB, MAINB = W2OFF + WB;
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       const int q = ptid + i * NPT;
       const int pix = q >> 2;
       const int py = pix / PW, px = pix - py * PW;
-      plds[i] = (q < NP) ? POFF + py * ROWP + px * PIXB + pc * 16 : trash;
+      plds[i] = (q < NP) ? POFF + py * ROWP + px * PPIX + pc * 16 : trash;
       prel[i] = (q < NP) ? ((py << 8) | px) : (0x7fff << 8);  // row 32767: outside every image, never valid
       pint |= ((q < NP && py >= 1 && py <= TH && px >= 1 && px <= TW) ? 1u : 0u) << i;
     }
@@ -548,7 +555,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       const int q = ptid + i * NPT;
       const int t = q / (BN * 4), r = q - t * (BN * 4);
       wsrc[i] = t * a.Ntot * 64 + r * 16;              // byte offset from the step's weight base
-      wlds[i] = t * (BN * PIXB) + (r >> 2) * PIXB + (r & 3) * 16;
+      const int wrow = r >> 2, wpc = M16 ? ((r & 3) ^ ((0x1230 >> (4 * ((wrow >> 2) & 3))) & 3)) : (r & 3);   // [0,3,2,1]
+      wlds[i] = t * (BN * WPIX) + wrow * WPIX + wpc * 16;
     }
 
     // ---- patch: per-unit pixel indices and validity, per-chunk source; one register set
@@ -685,6 +693,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   }
 
   // ============================================= CONSUMERS =============================================
+  if constexpr (!M16) {
   const int wm = wave / WN, wn = wave - wm * WN;
   const int lr = lane & 31, lh = lane >> 5;
   int laneA[MF], laneB[NF];
@@ -807,9 +816,141 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     __syncthreads();                                   // E3: the next unit's chunk 0 is in P0
     rd(0, 0, 0, fa[0], fb[0]);
   }
+  } else {
+  // ---- 16x16x32 form: the 128 x 64 wave tile is 8 x 4 blocks of 16 x 16; per tap (k = 32 = one whole chunk) 8 patch
+  // and 4 weight fragments feed 32 MFMAs.  Sub-step = one tap x one half of the pixel blocks (4 A + 4 B -> 16 MFMAs, 256
+  // matrix cycles, as before); fragments are read one sub-step ahead, the weight fragments of a tap once per two.
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int lc = lane & 15, lq = lane >> 4;
+  constexpr int MB = 8, NB = 4;
+  int laneA[MB], laneB[NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = (wm * MB + mb) * 16 + lc;
+    laneA[mb] = POFF + (m >> TWL) * ROWP + (m & (TW - 1)) * PPIX + lq * 16;
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    laneB[nb] = ((wn * NB + nb) * 16 + lc) * WPIX + ((lq ^ ((0x1230 >> (4 * ((lc >> 2) & 3))) & 3)) << 4);
+
+  f32x4 acc[MB][NB];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  uint4 fa[2][4], fb[3][NB];    // patch halves ping-pong per sub-step; weight fragments per tap ([0] primed before a step)
+  auto rdA = [&](int prow, int t, int hh, uint4 (&A)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) A[j] = *(const uint4*)(smem + prow + laneA[4 * hh + j] + t * PPIX);
+  };
+  auto rdB = [&](int wb, int t, uint4 (&Bf)[NB]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) Bf[nb] = *(const uint4*)(smem + wb + laneB[nb] + t * (BN * WPIX));
+  };
+  auto step = [&](auto TGc, int kc) {
+    constexpr int TG = decltype(TGc)::value;
+    const int prow = (kc & 1) * PB + TG * ROWP;
+    const int prow_next = (TG < 2) ? prow + ROWP : ((kc + 1) & 1) * PB;
+    constexpr int wb = TG < 2 ? TG * WB : W2OFF, wb_next = (TG + 1) % 3 < 2 ? ((TG + 1) % 3) * WB : W2OFF;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int t = i >> 1, hh = i & 1;
+      if (i + 1 < 6) {
+        rdA(prow, (i + 1) >> 1, (i + 1) & 1, fa[(i + 1) & 1]);
+        if (((i + 1) & 1) == 0) rdB(wb, (i + 1) >> 1, fb[(i + 1) >> 1]);
+      } else {
+        rdA(prow_next, 0, 0, fa[0]);
+        rdB(wb_next, 0, fb[0]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[4 * hh + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i & 1][j]),
+                                                                        __builtin_bit_cast(bf16x8, fb[t][nb]), acc[4 * hh + j][nb],
+                                                                        0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto stage_tile = [&](bool full) {   // bias, BN partial sums from the fp32 accumulators, tile -> LDS
+    const bool do_stats = (a.stats != nullptr);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = (wn * NB + nb) * 16 + lc;
+      const float bv = a.bias ? a.bias[un0 + n] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int m0 = (wm * MB + mb) * 16 + 4 * lq;        // the lane holds pixels m0 .. m0 + 3 of channel n
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[mb][nb][j] + bv;
+          if (!full) {   // rare: pixels past the image edge must not enter the statistics (they are never stored)
+            const int m = m0 + j;
+            v[j] = ((uy0 + (m >> TWL) < H) && (ux0 + (m & (TW - 1)) < W)) ? v[j] : 0.f;
+          }
+          s1 += v[j];
+          s2 = fmaf(v[j], v[j], s2);
+        }
+        char* const ob = ot + m0 * OP + n * E::ES;
+        uint32_t p01, p23;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p01) : "v"(v[0]), "v"(v[1]));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p23) : "v"(v[2]), "v"(v[3]));
+        *(uint16_t*)(ob) = (uint16_t)(p01 & 0xffffu);
+        *(uint16_t*)(ob + OP) = (uint16_t)(p01 >> 16);
+        *(uint16_t*)(ob + 2 * OP) = (uint16_t)(p23 & 0xffffu);
+        *(uint16_t*)(ob + 3 * OP) = (uint16_t)(p23 >> 16);
+      }
+      if (do_stats) {
+        s1 += __shfl_xor(s1, 16);
+        s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lq == 0) {
+          red[(wm * BN + n) * 2 + 0] = s1;
+          red[(wm * BN + n) * 2 + 1] = s2;
+        }
+      }
+    }
+  };
+
+  zero_acc();
+  __syncthreads();                                     // B0
+  rdA(0, 0, 0, fa[0]);
+  rdB(0, 0, fb[0]);
+  for (;;) {
+    const int un = u + GW;
+    const bool has_next = un < u_end;
+    int nmt = 0, nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
+    if (has_next) decode(un, nmt, nb, ny0, nx0, nn0);
+    for (int kc = 0; kc < nchunks; ++kc) {
+      step(std::integral_constant<int, 0>{}, kc);
+      __syncthreads();
+      step(std::integral_constant<int, 1>{}, kc);
+      __syncthreads();
+      step(std::integral_constant<int, 2>{}, kc);
+      __syncthreads();
+    }
+    const bool full = (uy0 + TH <= H) && (ux0 + TW <= W);
+    stage_tile(full);
+    __syncthreads();                                   // E1
+    if (full) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
+    if (!has_next) break;
+    zero_acc();
+    __syncthreads();                                   // E2
+    u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
+    __syncthreads();                                   // E3: the next unit's chunk 0 is in P0
+    rdA(0, 0, 0, fa[0]);
+    rdB(0, 0, fb[0]);
+  }
+  }
 }
 
-// ------------------------------------------------------------------------------------------------
 // Weight-stationary variant for the narrow, high-resolution layers (Cin <= 2 chunks, 64 output channels per
 // tile: the 3->64 stem, the 64->64 convs of down1/up4 and the 64->128 concat gradient): these are HBM-bound
 // (K = 9*Cin is tiny), so the structure is built around keeping the memory pipes busy instead of the
@@ -1090,12 +1231,13 @@ int launch_ws(ConvArgs a, hipStream_t st) {
   return 0;
 }
 
-template <int TWL, bool PRO, int BN>
-int launch_pipe(ConvArgs a, hipStream_t st) {
+template <int TWL, bool PRO, int BN, bool M16>
+int launch_pipe_m(ConvArgs a, hipStream_t st) {
   constexpr int BM = 32768 / BN, NTHR = 512;
   constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
-  constexpr int ROWP = (PW * PIXB + 255) & ~255;
-  constexpr size_t lds = 3 * (size_t)(3 * BN * PIXB) + 2 * (size_t)PH * ROWP + (NTHR / 2) * 16;   // + producers' trash slots
+  constexpr int PPIX = M16 ? 96 : PIXB, WPIX = M16 ? 64 : PIXB;
+  constexpr int ROWP = (PW * PPIX + 255) & ~255;
+  constexpr size_t lds = 3 * (size_t)(3 * BN * WPIX) + 2 * (size_t)PH * ROWP + (NTHR / 2) * 16;   // + producers' trash slots
   static_assert(lds <= 160 * 1024, "conv3x3_pipe: LDS exceeds 160 KiB");
   a.twl = TWL;
   a.tiles_x = cdiv(a.W, TW);
@@ -1105,7 +1247,7 @@ int launch_pipe(ConvArgs a, hipStream_t st) {
   int gw = num_cus() / 8;                                  // one 8-wave workgroup per CU
   if (gw > per_xcd) gw = per_xcd;
   a.persistent = 1;
-  auto kern = conv3x3_pipe_kernel<TWL, PRO, BN>;
+  auto kern = conv3x3_pipe_kernel<TWL, PRO, BN, M16>;
   static bool attr_set[SEGK_MAX_DEVICES] = {};
   const int dev = segk_device_index();
   if (!attr_set[dev]) {
@@ -1116,6 +1258,16 @@ int launch_pipe(ConvArgs a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(8 * gw), dim3(NTHR), lds, st, a);
   SEGK_CHECK_LAUNCH("conv3x3_pipe");
   return 0;
+}
+
+template <int TWL, bool PRO, int BN>
+int launch_pipe(ConvArgs a, hipStream_t st) {
+  // 16x16x32 consumers where the layer is MFMA-bound (K = 9 Cin long: same-box A/B 1024->1024@16 119 vs 132 us,
+  // 512->512@32 128 vs 135, 256->256@64 141 vs 143); the shallower layers are bound by staging and the epilogue, where
+  // the wider patch pitch costs more than the shape gains (128->128@128 164 vs 160, 128->64@256 382 vs 358)
+  static const char* const force = getenv("SEGK_PIPE_MFMA");  // A/B switch for tools/kbench.py: "16" or "32"
+  const bool m16 = force ? (force[0] == '1') : (a.CA + a.CB >= 256);
+  return m16 ? launch_pipe_m<TWL, PRO, BN, true>(a, st) : launch_pipe_m<TWL, PRO, BN, false>(a, st);
 }
 
 template <typename T, int GEO, int TWL, int WM, int WN, int MF, int NF, int PBUF, bool PRO>
