@@ -33,6 +33,7 @@ SIGNATURES = {
     "segk_convt2x2_fwd": (_i, [_vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_convt2x2_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_wgrad_tiles": (_i, [_i, _i, _i, _i, _i]),
+    "segk_wgrad_split": (_i, [_i, _i, _i, _i, _i, _i]),
     "segk_wgrad": (_i, [_vp, _vp, _vp, _fp, _fp, _fp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_wgrad_reduce": (_i, [_fp, _i, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_bn_finalize": (_i, [_fp, _i, _i, _i, _d, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _fp, _fp, _fp, _fp, _vp]),

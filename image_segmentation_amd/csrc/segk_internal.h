@@ -54,6 +54,7 @@ struct WgradArgs {
   int S;                // split-K factor over spatial tiles
 };
 int segk_wgrad_launch(const WgradArgs& a, int geo, int dtype, hipStream_t st);
+int segk_wgrad_wc(int CD, int CA, int CB, int geo, int dtype);
 
 // producer/consumer bf16 GEMM of the 1x1 geometry (gemm.hip)
 struct GemmArgs {

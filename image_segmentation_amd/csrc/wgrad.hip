@@ -15,6 +15,7 @@
 // fp32: exact 32x32x2 MFMA, one ds_read_b32 per operand (lanes = 32 contiguous channels).
 // Each wave owns a 32x32 (n,k) block for ALL taps (9 accumulators); split-K over spatial tiles writes
 // fp32 slabs that segk_wgrad_reduce sums in fixed order (bit-stable, no atomics).
+#include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
 #include "segk_internal.h"
@@ -246,9 +247,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
 // fragment per dz row, in registers, with the lane's own channel constants, and the shifted operand (dz)
 // needs no transform and gets exact-zero halos from the zero page.  Swapping A/B in the MFMA keeps the
 // accumulator oriented [co][ci]; the tap index mirrors (tap -> 8 - tap).
+// WC x WI waves of 32 x 32 blocks make the workgroup's (n, k) tile; 4 x 2 (eight waves, one workgroup per CU) moves
+// 0.7 of the LDS-DMA bytes per FLOP of two 2 x 2 workgroups: the deep layers are bound by that L2 -> LDS fill rate.
 template <int WC, int WI, bool PRO>
-__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
+__global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma_kernel(const WgradArgs a) {
   typedef bf16_t T;
+  constexpr int NWV = WC * WI > 4 ? WC * WI : 4;          // waves per workgroup
   constexpr int R = 8, NTAPS = 9, BLKP = 64;
   constexpr int WU = PRO ? WI : WC, WV = PRO ? WC : WI;
   constexpr int NU = R * 16, NV = 192;                    // pixels per block region (patch: 180 used)
@@ -283,8 +287,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     const int y0 = (rem / tiles_x) * R, x0 = (rem % tiles_x) * 16;
     char* const bb = smem + bufsel * BUF;
 #pragma unroll
-    for (int i = 0; i < (NINSTR + 3) / 4; ++i) {
-      const int j = wave + 4 * i;                          // wave-uniform
+    for (int i = 0; i < (NINSTR + NWV - 1) / NWV; ++i) {
+      const int j = wave + NWV * i;                        // wave-uniform
       if (j >= NINSTR) break;
       const char* src;
       char* dst;
@@ -474,7 +478,7 @@ int launch_dma(const WgradArgs& a, hipStream_t st) {
       SEGK_FAIL(-3, "wgrad_dma: cannot raise dynamic LDS limit");
     attr_set[dev_] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3((WC * WI > 4 ? WC * WI : 4) * 64), lds, st, a);
   SEGK_CHECK_LAUNCH("wgrad_dma");
   return 0;
 }
@@ -508,6 +512,7 @@ int launch_geo(const WgradArgs& a, hipStream_t st) {
   const bool wi2 = a.CA % 64 == 0 && a.CB % 64 == 0;
   if constexpr (GEO == 0 && sizeof(T) == 2) {
     if (a.zeros) {           // bf16 3x3: LDS-DMA kernel (needs the caller's zero page)
+      if (segk_wgrad_wc(a.CD, a.CA, a.CB, 0, SEGK_DT_BF16) == 4) return launch_dma_pro<4, 2>(a, st);
       if (wc2 && wi2) return launch_dma_pro<2, 2>(a, st);
       if (wc2) return launch_dma_pro<2, 1>(a, st);
       if (wi2) return launch_dma_pro<1, 2>(a, st);
@@ -528,6 +533,25 @@ int launch_t(const WgradArgs& a, int geo, hipStream_t st) {
 }
 
 }  // namespace
+
+// 32-channel blocks of the dz operand per workgroup (the host sizes the split-K slabs with it: segk_wgrad_split)
+int segk_wgrad_wc(int CD, int CA, int CB, int geo, int dtype) {
+  static const bool off = getenv("SEGK_WGRAD_NO_WC4") != nullptr;      // A/B switch for tools/kbench.py
+  if (geo == 0 && dtype == SEGK_DT_BF16 && !off && CD % 128 == 0 && CA % 64 == 0 && CB % 64 == 0) return 4;
+  return CD % 64 == 0 ? 2 : 1;
+}
+// split-K factor over spatial tiles: enough workgroups to fill the chip (two 4-wave workgroups or one 8-wave workgroup
+// per CU), never more slabs than tiles
+int segk_wgrad_split(int tiles, int CD, int CA, int CB, int geo, int dtype) {
+  if (tiles <= 0 || CD <= 0 || CA <= 0 || CB < 0) return 0;
+  const int wc = segk_wgrad_wc(CD, CA, CB, geo, dtype);
+  const int wi = (CA % 64 == 0 && CB % 64 == 0) ? 2 : 1;
+  const int nct = (CD / (32 * wc)) * ((CA + CB) / (32 * wi));
+  const int target = wc == 4 ? 256 : 512;
+  int S = nct < target ? target / nct : 1;
+  if (S > tiles) S = tiles;
+  return S < 1 ? 1 : S;
+}
 
 int segk_wgrad_tiles(int B, int H, int W, int geo, int dtype) {
   const bool bf = dtype == SEGK_DT_BF16;

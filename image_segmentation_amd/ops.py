@@ -304,10 +304,7 @@ def wgrad(dz_ptr, CDp, ptrA, CAp, ptrB, CBp, B, H, W, geo, dtype, dev, scale=Non
     P, e = B * H * W, _es(dtype)
     pk = P * (4 if geo == 2 else 1)
     tiles = _lib.query("segk_wgrad_tiles", B, H, W, geo, _DT[dtype])
-    wc = 2 if CDp % 64 == 0 else 1
-    wi = 2 if (CAp % 64 == 0 and CBp % 64 == 0) else 1
-    nct = (CDp // (32 * wc)) * ((CAp + CBp) // (32 * wi))
-    S = max(1, min(tiles, 512 // nct if nct < 512 else 1))
+    S = _lib.query("segk_wgrad_split", tiles, CDp, CAp, CBp, geo, _DT[dtype])
     slabs = _f32(S * CDp * taps * (CAp + CBp), dev)
     tag = {0: "wgrad3x3", 1: "wgrad1x1", 2: "wgrad_convt"}[geo]
     with _span(tag, 2.0 * P * taps * cd * ck, (P * cd + pk * ck) * e + 4.0 * taps * cd * ck):

@@ -93,6 +93,9 @@ int segk_convt2x2_dgrad(const void* dout, const void* wpacked, void* din, int B,
  * dz := layer input [B,H,W,CD], srcA := output gradient [B,2H,2W,CA], grad IOHW [CD][CA][2][2].
  * scale/shift: BatchNorm+ReLU prologue on srcA (the conv input is relu(bn(z)) of the previous conv). */
 int segk_wgrad_tiles(int B, int H, int W, int geo, int dtype);
+/* split-K factor S the host sizes the slab buffer with ([S][CD][taps][CA+CB] fp32) for `tiles` = segk_wgrad_tiles():
+ * enough workgroups to fill the chip for this layer's (n, k) tiling, never more slabs than tiles; 0 for invalid input */
+int segk_wgrad_split(int tiles, int CD, int CA, int CB, int geo, int dtype);
 int segk_wgrad(const void* dz, const void* srcA, const void* srcB, const float* scale, const float* shift,
                float* slabs, const void* zeros64, int S, int B, int H, int W, int CD, int CA, int CB, int geo,
                int dtype, segk_stream_t s);   /* zeros64: >= 64 zero bytes in device memory (halo source of the
