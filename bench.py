@@ -94,7 +94,12 @@ def main():
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
         env.setdefault("OMP_NUM_THREADS", "8")
-        sys.exit(subprocess.run(cmd, env=env).returncode)
+        # rank 0's JSON line is relayed to stdout; anything else a rank writes there (the gloo transport of the rehearsal
+        # mode prints connection notes to stdout from C++) goes to stderr, so stdout carries exactly ONE line
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        for line in r.stdout.splitlines():
+            print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+        sys.exit(r.returncode)
 
     import torch
     import torch.distributed as dist

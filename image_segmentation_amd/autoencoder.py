@@ -156,6 +156,7 @@ class ReconstructionAutoencoder(_FusedBase):
         return _set_dtype(self, dtype)
 
     def forward(self, x):
+        ops.repack_stale(self)
         with ops.defer_batch_counters():
             bottleneck, _s3, _s2, _s1 = self.encoder(x)
             decoded = self.decoder(bottleneck)
@@ -226,6 +227,7 @@ class SegmentationAutoencoder(_FusedBase):
         return _set_dtype(self, dtype)
 
     def forward(self, x):
+        ops.repack_stale(self)
         with ops.defer_batch_counters():
             bottleneck, skip3, skip2, skip1 = self.encoder(x)
             return self.decoder(bottleneck, skip3, skip2, skip1, head=self.finalConv)

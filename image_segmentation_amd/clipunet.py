@@ -151,5 +151,6 @@ class ClipUNet(_FusedBase):
         return self
 
     def forward(self, x):
+        ops.repack_stale(self)
         x, skips = self.encoder(x)
         return self.decoder(x, skips, head=self.output_layer)

@@ -84,14 +84,13 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restri
 // step otherwise).  A block owns a 32 (output channels) x 32 (padded input channels) x 9 tile: coalesced fp32 reads
 // into LDS, then per tap one contiguous 32 x 32 block of the forward layout and one of the data-gradient layout.
 template <typename T>
-__global__ __launch_bounds__(256) void pack_conv3x3_both_kernel(const float* __restrict__ w, T* __restrict__ df,
-                                                                T* __restrict__ dd, int Cout, int CA, int CB, int Coutp,
-                                                                int CAp, int CBp) {
+__device__ __forceinline__ void pack_conv3x3_both_block(const float* __restrict__ w, T* __restrict__ df, T* __restrict__ dd,
+                                                        int Cout, int CA, int CB, int Coutp, int CAp, int CBp, int bx, int by,
+                                                        float (&tile)[32][32 * 9 + 1]) {
   using E = ET<T>;
   constexpr int CH = E::CH, VEC = E::VEC, VPR = 32 / VEC;     // 16-byte vectors per 32-element row
-  __shared__ float tile[32][32 * 9 + 1];
   const int Cin = CA + CB, Cinp = CAp + CBp;
-  const int kp0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int kp0 = bx * 32, co0 = by * 32;
   const int ci0 = dual_map(kp0, CA, CAp, CB, CBp), ci31 = dual_map(kp0 + 31, CA, CAp, CB, CBp);
   if (ci0 >= 0 && ci31 == ci0 + 31 && co0 + 32 <= Cout && (Cin & 3) == 0 && (ci0 & 3) == 0) {
     // whole tile inside the parameter: every output channel's 32 x 9 floats are contiguous and 16-byte aligned
@@ -127,6 +126,25 @@ __global__ __launch_bounds__(256) void pack_conv3x3_both_kernel(const float* __r
       *(uint4*)(dd + (((long)(co / CH) * 9 + tap) * Cinp + kp0 + kk) * CH + co % CH) = pack16<T>(f);
     }
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv3x3_both_kernel(const float* __restrict__ w, T* __restrict__ df,
+                                                                T* __restrict__ dd, int Cout, int CA, int CB, int Coutp,
+                                                                int CAp, int CBp) {
+  __shared__ float tile[32][32 * 9 + 1];
+  pack_conv3x3_both_block<T>(w, df, dd, Cout, CA, CB, Coutp, CAp, CBp, blockIdx.x, blockIdx.y, tile);
+}
+// Every 3x3 weight of a model in ONE launch (segk_pack_conv3x3_multi): `table` lists the tensors, a block finds its
+// tensor by its first block index (entries sorted, <= 64 of them) and runs the same 32 x 32 x 9 tile routine.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv3x3_multi_kernel(const SegkPackEntry* __restrict__ table, int n) {
+  __shared__ float tile[32][32 * 9 + 1];
+  int e = 0;
+  for (int i = 1; i < n; ++i) e = ((int)blockIdx.x >= table[i].block0) ? i : e;     // scalar loop (uniform)
+  const SegkPackEntry t = table[e];
+  const int lid = blockIdx.x - t.block0, gx = (t.CAp + t.CBp) / 32;
+  pack_conv3x3_both_block<T>(t.w, (T*)t.dst_fwd, (T*)t.dst_dgrad, t.Cout, t.CA, t.CB, t.Coutp, t.CAp, t.CBp, lid % gx, lid / gx,
+                             tile);
 }
 
 // ConvTranspose2d(k=2,s=2) weight [Cin][Cout][2][2] -> packed.
@@ -262,6 +280,17 @@ int segk_pack_conv3x3_both_impl(const float* w, void* dst_fwd, void* dst_dgrad, 
     hipLaunchKernelGGL(pack_conv3x3_both_kernel<float>, grid, dim3(256), 0, st, w, (float*)dst_fwd, (float*)dst_dgrad, Cout, CA,
                        CB, Coutp, CAp, CBp);
   SEGK_CHECK_LAUNCH("pack_conv3x3_both");
+  return 0;
+}
+
+int segk_pack_conv3x3_multi_impl(const void* table, int n, int total_blocks, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(table && n > 0 && n <= 64 && total_blocks > 0, "pack_conv3x3_multi: bad arguments");
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "pack_conv3x3_multi: bad dtype %d", dtype);
+  if (dtype == SEGK_DT_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_multi_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, (const SegkPackEntry*)table, n);
+  else
+    hipLaunchKernelGGL(pack_conv3x3_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, st, (const SegkPackEntry*)table, n);
+  SEGK_CHECK_LAUNCH("pack_conv3x3_multi");
   return 0;
 }
 

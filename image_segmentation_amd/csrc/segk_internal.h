@@ -41,6 +41,17 @@ int segk_conv_writes_act(int cin_p, int n_p, int dtype); // the layer's kernel c
 int segk_conv_bm(int geo, int unit);      // pixels per tile for a layer with N = unit output channels
 int segk_conv_twl(int bm, int W);         // log2 tile width
 
+// one 3x3 weight of segk_pack_conv3x3_multi's device table (64 bytes; the host builds it as 8 int64 words)
+struct SegkPackEntry {
+  const float* w;       // OIHW fp32 parameter
+  void* dst_fwd;        // forward layout
+  void* dst_dgrad;      // data-gradient layout (or null)
+  int Cout, CA, CB, Coutp, CAp, CBp;
+  int block0;           // first block of this tensor in the launch (entries sorted by it)
+  int pad_[3];
+};
+static_assert(sizeof(SegkPackEntry) == 64, "SegkPackEntry is 64 bytes");
+
 struct WgradArgs {
   const void* dz;       // NHWC [B,H,W,CD]        (un-shifted operand; rows of dW)
   const void* srcA;     // NHWC [B,H,W,CA]        (tap-shifted operand; columns of dW)

@@ -543,7 +543,7 @@ int segk_wgrad_wc(int CD, int CA, int CB, int geo, int dtype) {
 // split-K factor over spatial tiles: enough workgroups to fill the chip (two 4-wave workgroups or one 8-wave workgroup
 // per CU), never more slabs than tiles
 int segk_wgrad_split(int tiles, int CD, int CA, int CB, int geo, int dtype) {
-  if (tiles <= 0 || CD <= 0 || CA <= 0 || CB < 0) return 0;
+  if (tiles <= 0 || CD <= 0 || CA <= 0 || CB < 0 || CD % 32 || CA % 32 || CB % 32) return 0;   // channel counts are padded
   const int wc = segk_wgrad_wc(CD, CA, CB, geo, dtype);
   const int wi = (CA % 64 == 0 && CB % 64 == 0) ? 2 : 1;
   const int nct = (CD / (32 * wc)) * ((CA + CB) / (32 * wi));

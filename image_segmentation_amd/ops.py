@@ -150,9 +150,11 @@ class PackCache:
 
     def __init__(self):
         self._c = {}
+        self.pairs = {}      # key_a -> (key_b, param, CA, CB, dtype): what repack_stale() refreshes in one launch
 
-    def get_pair(self, key_a, key_b, param, builder):
-        """Two packed copies made by one builder call (returns the first; the second is served by get(key_b))."""
+    def get_pair(self, key_a, key_b, param, builder, meta=None):
+        """Two packed copies made by one builder call (returns the first; the second is served by get(key_b)).
+        meta=(CA, CB, dtype) registers the pair of a 3x3 weight for repack_stale()."""
         ver = (param._version, param.data_ptr(), param.device, _OPT_EPOCH[0] if param.requires_grad else -1)
         hit = self._c.get(key_a)
         if hit is None or hit[0] != ver:
@@ -160,6 +162,8 @@ class PackCache:
             hit = (ver, a)
             self._c[key_a] = hit
             self._c[key_b] = (ver, b)
+            if meta is not None:
+                self.pairs[key_a] = (key_b, param) + tuple(meta)
         return hit[1]
 
     def get(self, key, param, builder):
@@ -195,6 +199,61 @@ def pack_conv_both(w, CA, CB, dtype):
     _lib.call("segk_pack_conv3x3_both", wf.data_ptr(), both.data_ptr(), both[n:].data_ptr(), Cout, CA, CB, Coutp, CAp, CBp,
               _DT[dtype], _stream())
     return both[:n], both[n:]
+
+
+def repack_stale(model):
+    """Refresh every stale (forward, data-gradient) pair of 3x3 weights under `model` with ONE launch
+    (segk_pack_conv3x3_multi) instead of one per weight: called at the top of a model's forward, it does nothing until
+    an optimizer step (or invalidate_packed_weights) moved the epoch.  The pairs are those DoubleConvFn registered on its
+    first training forward; their destination buffers are re-used (every consumer is ordered on the launch stream)."""
+    st = model.__dict__.get("_segk_pack_state")
+    if st is None:
+        st = model.__dict__["_segk_pack_state"] = {"epoch": _OPT_EPOCH[0], "caches": None, "tables": {}}
+        return                      # nothing can be registered before the first forward
+    if st["epoch"] == _OPT_EPOCH[0]:
+        return
+    st["epoch"] = _OPT_EPOCH[0]
+    if st["caches"] is None:
+        st["caches"] = [m.cache for m in model.modules() if isinstance(getattr(m, "cache", None), PackCache)]
+    groups = {}
+    for cache in st["caches"]:
+        for key_a, (key_b, param, CA, CB, dtype) in cache.pairs.items():
+            ha, hb = cache._c.get(key_a), cache._c.get(key_b)
+            if ha is None or hb is None or not param.is_cuda or param.dtype != torch.float32 or not param.is_contiguous():
+                continue
+            ver = (param._version, param.data_ptr(), param.device, _OPT_EPOCH[0] if param.requires_grad else -1)
+            if ha[0] == ver and hb[0] == ver:
+                continue
+            Cout = param.shape[0]
+            n = (pad32(CA) + (pad32(CB) if CB else 0)) * 9 * pad32(Cout)
+            if ha[1].numel() != n or hb[1].numel() != n or ha[1].dtype != dtype or hb[1].dtype != dtype:
+                continue
+            groups.setdefault((dtype, param.device), []).append((cache, key_a, key_b, ver, param, ha[1], hb[1], CA, CB))
+    for (dtype, dev), items in groups.items():
+        if len(items) < 2:
+            continue                 # a single weight goes through the per-weight path
+        for c0 in range(0, len(items), 64):
+            chunk = items[c0:c0 + 64]
+            sig = tuple((it[4].data_ptr(), it[5].data_ptr(), it[6].data_ptr(), it[7], it[8]) for it in chunk)
+            tab = st["tables"].get((dtype, dev, c0))
+            if tab is None or tab[0] != sig:
+                import numpy as np
+                words = np.zeros((len(chunk), 8), dtype=np.int64)
+                ints = words.view(np.int32).reshape(len(chunk), 16)
+                blk = 0
+                for i, (_, _, _, _, param, a, b, CA, CB) in enumerate(chunk):
+                    Cout = param.shape[0]
+                    Coutp, CAp, CBp = pad32(Cout), pad32(CA), (pad32(CB) if CB else 0)
+                    words[i, 0], words[i, 1], words[i, 2] = param.data_ptr(), a.data_ptr(), b.data_ptr()
+                    ints[i, 6:13] = (Cout, CA, CB, Coutp, CAp, CBp, blk)
+                    blk += (CAp + CBp) // 32 * (Coutp // 32)
+                tab = (sig, torch.from_numpy(words).to(dev), blk)
+                st["tables"][(dtype, dev, c0)] = tab
+            with torch.cuda.device(dev):
+                _lib.call("segk_pack_conv3x3_multi", tab[1].data_ptr(), len(chunk), tab[2], _DT[dtype], _stream())
+            for cache, key_a, key_b, ver, _, a, b, _, _ in chunk:
+                cache._c[key_a] = (ver, a)
+                cache._c[key_b] = (ver, b)
 
 
 def pack_convt(w, dtype, mode):
@@ -596,8 +655,10 @@ class DoubleConvFn(torch.autograd.Function):
         xb_t, pB, CBp = (None, 0, 0) if xb is None else _raw(xb, dtype)
         want_grad = any(ctx.needs_input_grad)
         if training and want_grad:     # a backward will follow: both layouts in one pass per weight
-            w1p = mod.cache.get_pair(("w1f", dtype), ("w1d", dtype), w1, lambda: pack_conv_both(w1, CA, CB, dtype))
-            w2p = mod.cache.get_pair(("w2f", dtype), ("w2d", dtype), w2, lambda: pack_conv_both(w2, Cout, 0, dtype))
+            w1p = mod.cache.get_pair(("w1f", dtype), ("w1d", dtype), w1, lambda: pack_conv_both(w1, CA, CB, dtype),
+                                     meta=(CA, CB, dtype))
+            w2p = mod.cache.get_pair(("w2f", dtype), ("w2d", dtype), w2, lambda: pack_conv_both(w2, Cout, 0, dtype),
+                                     meta=(Cout, 0, dtype))
         else:
             w1p = mod.cache.get(("w1f", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 0))
             w2p = mod.cache.get(("w2f", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 0))

@@ -109,6 +109,7 @@ class unet(_FusedBase):
         return self
 
     def forward(self, x):
+        ops.repack_stale(self)               # after an optimizer step: all 18 weight pairs re-packed by one launch
         with ops.defer_batch_counters():     # one fused update of the 18 num_batches_tracked counters
             return self._forward(x)
 

@@ -52,6 +52,11 @@ int segk_pack_conv_weight(const float* w, void* dst, int Cout, int CA, int CB, i
  * fp32 parameter (training re-packs after every optimizer step); dst_dgrad may be NULL */
 int segk_pack_conv3x3_both(const float* w, void* dst_fwd, void* dst_dgrad, int Cout, int CA, int CB, int Coutp, int CAp,
                            int CBp, int dtype, segk_stream_t s);
+/* segk_pack_conv3x3_both for up to 64 weights in ONE launch (every 3x3 weight of a model after an optimizer step).
+ * table: device array of n 64-byte entries { const float* w; void* dst_fwd; void* dst_dgrad; int32 Cout, CA, CB, Coutp,
+ * CAp, CBp; int32 block0; int32 pad[3] } sorted by block0 = first block of the tensor, a tensor taking
+ * (CAp+CBp)/32 * Coutp/32 blocks; total_blocks = their sum.  The table must stay valid until the launch has run. */
+int segk_pack_conv3x3_multi(const void* table, int n, int total_blocks, int dtype, segk_stream_t s);
 /* ConvTranspose2d(k=2,s=2) weight IOHW fp32 [Cin][Cout][2][2] -> MFMA layout; mode 0 forward, 1 data-gradient */
 int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cinp, int Coutp, int mode, int dtype,
                            segk_stream_t s);
