@@ -442,6 +442,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 // 1.60 PFLOP/s at this wave tile).  A 16x16x32 operand is 16 rows x one whole 64-byte chunk, so the LDS image changes:
 // patch pixels at a 96-byte pitch (conflict-free for 16 consecutive pixels at any tap shift), weight rows unpadded with
 // the 16-byte piece index XOR-ed by [0,3,2,1][(row >> 2) & 3] (conflict-free, rows never shift).
+// Diagnostic build only (-DSEGK_PIPE_STAMPS, tools/stamp_build.sh): per-wave cycle sums of the loop's phases, written
+// over the statistics buffer by lane 0 of every wave; the shipped library contains no stamp.
+#ifdef SEGK_PIPE_STAMPS
+#define PIPE_STAMP(i)                                                                     \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned long long t_;                                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+    stamp_sum[i] += t_ - stamp_last;                                                      \
+    stamp_last = t_;                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#define PIPE_STAMP_OUT()                                                                  \
+  do {                                                                                    \
+    if (a.stats != nullptr && lane == 0) {                                                \
+      unsigned long long* o_ = (unsigned long long*)a.stats + ((size_t)blockIdx.x * 8 + wave) * 8; \
+      for (int i_ = 0; i_ < 6; ++i_) o_[i_] = stamp_sum[i_];                              \
+      o_[6] = stamp_last - stamp_t0;                                                      \
+    }                                                                                     \
+  } while (0)
+#else
+#define PIPE_STAMP(i) do {} while (0)
+#define PIPE_STAMP_OUT() do {} while (0)
+#endif
+#ifndef PIPE_ABL
+#define PIPE_ABL 0     // diagnostic ablations (results are wrong): 1 producers skip LDS stores, 2 skip global loads, 4 consumers re-use fragments
+#endif
+
 template <int TWL, bool PRO, int BN, bool M16>
 __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) {
   using T = bf16_t;
@@ -492,6 +520,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   };
   int ub, uy0, ux0, un0, umt;
   decode(u, umt, ub, uy0, ux0, un0);
+#ifdef SEGK_PIPE_STAMPS
+  unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+  const unsigned long long stamp_t0 = stamp_last;
+#endif
 
   // ---- the part of the epilogue all 512 threads run: BN-statistics reduction over the consumer rows and
   // the 16-byte coalesced NHWC stores of the staged tile
@@ -501,6 +534,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   float* const red = (float*)(ot + BM * OP);
   auto store_tile = [&](auto FULLc) {
     constexpr bool FULL = decltype(FULLc)::value;
+#ifndef SEGK_PIPE_STAMPS
     if (a.stats != nullptr && tid < BN) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -511,6 +545,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       float2* dst = (float2*)a.stats + (size_t)umt * a.Ntot + un0 + tid;
       *dst = make_float2(t1, t2);
     }
+#endif
     constexpr int CPR = BN * E::ES / 16;   // 16-byte chunks per pixel row of the tile
     constexpr int NST = BM * CPR / NTHR;
     const int cc = tid & (CPR - 1);
@@ -585,6 +620,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       else { base = (const T*)a.srcB; C = a.CB; coff = (kc - nchA) * E::CH; }
       base += coff + pc * E::VEC;
       pl_aoff = (kc < nchA) ? coff + pc * E::VEC : -1;      // act_out mirrors srcA only
+      if (PIPE_ABL & 2) return;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) preg[i] = *(const u32x4*)(base + (size_t)(unsigned)(plin[i] * C));
       if (PRO) {
@@ -596,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       }
     };
     auto patch_store = [&](int pboff) {
+      if (PIPE_ABL & 1) return;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         u32x4 v = preg[i];
@@ -629,11 +666,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       if (cu_ok) {
         const char* wb = (const char*)a.w + ((size_t)(cu_step * 3) * a.Ntot + cu_n0) * 64;
 #pragma unroll
-        for (int i = 0; i < NWL; ++i) R[i] = *(const u32x4*)(wb + wsrc[i]);
+        for (int i = 0; i < NWL; ++i)
+          if (!(PIPE_ABL & 2)) R[i] = *(const u32x4*)(wb + wsrc[i]);
         if (++cu_step == nsteps) { cu_step = 0; cu_n0 = nn0; cu_ok = has_next; }
       }
     };
     auto store_w = [&](int ring, const u32x4 (&R)[NWL]) {
+      if (PIPE_ABL & 1) return;
 #pragma unroll
       for (int i = 0; i < NWL; ++i) *(u32x4*)(smem + wring(ring) + wlds[i]) = R[i];
     };
@@ -656,6 +695,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     fetch_w(wreg[0]);
     patch_load(1);
     __syncthreads();                                   // B0
+    PIPE_STAMP(5);
     for (;;) {
       const int un = u + GW;
       has_next = un < u_end;
@@ -665,30 +705,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
         // step TG0: ring slot 2 <- weights of step s+2; fetch step s+4
         store_w(2, wreg[2]);
         fetch_w(wreg[1]);
+        PIPE_STAMP(0);
         __syncthreads();
+        PIPE_STAMP(1);
         // step TG1: the next chunk's patch, ring slot 0
         if (kc + 1 < nchunks) patch_store(((kc + 1) & 1) * PB);
         store_w(0, wreg[0]);
         fetch_w(wreg[2]);
+        PIPE_STAMP(0);
         __syncthreads();
+        PIPE_STAMP(1);
         // step TG2: ring slot 1; fetch the patch two chunks ahead (the next unit's chunk 0 from the
         // second-to-last chunk; the last chunk fetches nothing: its registers are stored after the epilogue)
         store_w(1, wreg[1]);
         fetch_w(wreg[0]);
         if (kc + 2 < nchunks) patch_load(kc + 2);
         else if (kc + 2 == nchunks && has_next) { patch_unit(nb, ny0, nx0, nn0); patch_load(0); }
+        PIPE_STAMP(0);
         __syncthreads();
+        PIPE_STAMP(1);
       }
       __syncthreads();                                 // E1: the consumers have staged the output tile
+      PIPE_STAMP(2);
       if ((uy0 + TH <= H) && (ux0 + TW <= W)) store_tile(std::true_type{});
       else store_tile(std::false_type{});
+      PIPE_STAMP(3);
       if (!has_next) break;
       __syncthreads();                                 // E2: tile consumed, [P0 | P1 | W2] may be rewritten
       patch_store(0);                                  // next unit's chunk 0
       patch_load(1);                                   // and its chunk 1, stored during its step 1
       u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
       __syncthreads();                                 // E3
+      PIPE_STAMP(4);
     }
+    PIPE_STAMP_OUT();
     return;
   }
 
@@ -842,10 +892,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   };
   uint4 fa[2][4], fb[3][NB];    // patch halves ping-pong per sub-step; weight fragments per tap ([0] primed before a step)
   auto rdA = [&](int prow, int t, int hh, uint4 (&A)[4]) {
+    if (PIPE_ABL & 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(A[j].x), "+v"(A[j].y), "+v"(A[j].z), "+v"(A[j].w));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) A[j] = *(const uint4*)(smem + prow + laneA[4 * hh + j] + t * PPIX);
   };
   auto rdB = [&](int wb, int t, uint4 (&Bf)[NB]) {
+    if (PIPE_ABL & 4) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(Bf[nb].x), "+v"(Bf[nb].y), "+v"(Bf[nb].z), "+v"(Bf[nb].w));
+      return;
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) Bf[nb] = *(const uint4*)(smem + wb + laneB[nb] + t * (BN * WPIX));
   };
@@ -875,7 +935,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto stage_tile = [&](bool full) {   // bias, BN partial sums from the fp32 accumulators, tile -> LDS
+  auto stage_tile = [&](auto FULLc) {   // bias, BN partial sums from the fp32 accumulators, tile -> LDS
+    constexpr bool full = decltype(FULLc)::value;      // compile time: a run-time test here is a branch per value
     const bool do_stats = (a.stats != nullptr);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -920,6 +981,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
 
   zero_acc();
   __syncthreads();                                     // B0
+  PIPE_STAMP(5);
   rdA(0, 0, 0, fa[0]);
   rdB(0, 0, fb[0]);
   for (;;) {
@@ -929,25 +991,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     if (has_next) decode(un, nmt, nb, ny0, nx0, nn0);
     for (int kc = 0; kc < nchunks; ++kc) {
       step(std::integral_constant<int, 0>{}, kc);
+      PIPE_STAMP(0);
       __syncthreads();
+      PIPE_STAMP(1);
       step(std::integral_constant<int, 1>{}, kc);
+      PIPE_STAMP(0);
       __syncthreads();
+      PIPE_STAMP(1);
       step(std::integral_constant<int, 2>{}, kc);
+      PIPE_STAMP(0);
       __syncthreads();
+      PIPE_STAMP(1);
     }
     const bool full = (uy0 + TH <= H) && (ux0 + TW <= W);
-    stage_tile(full);
+    if (full) stage_tile(std::true_type{});
+    else stage_tile(std::false_type{});
+    PIPE_STAMP(2);
     __syncthreads();                                   // E1
     if (full) store_tile(std::true_type{});
     else store_tile(std::false_type{});
+    PIPE_STAMP(3);
     if (!has_next) break;
     zero_acc();
     __syncthreads();                                   // E2
     u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
     __syncthreads();                                   // E3: the next unit's chunk 0 is in P0
+    PIPE_STAMP(4);
     rdA(0, 0, 0, fa[0]);
     rdB(0, 0, fb[0]);
   }
+  PIPE_STAMP_OUT();
   }
 }
 

@@ -31,9 +31,11 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
   }
 }
 
-template <typename T, int GEO> struct WG {
+template <typename T, int GEO, int WC = 1> struct WG {
   static constexpr bool BF = (sizeof(T) == 2);
-  static constexpr int R = (GEO == 2) ? (BF ? 4 : 2) : (BF ? 8 : 4);   // dz rows per tile (16 px wide)
+  // dz rows per tile (16 px wide).  The ConvTranspose 4 x 2 configuration is latency-bound (one 8-wave workgroup per CU,
+  // synchronous staging): 8 rows per tile halve its iterations
+  static constexpr int R = (GEO == 2) ? (BF ? (WC == 4 ? 8 : 4) : 2) : (BF ? 8 : 4);
   static constexpr int NTAPS = GEO == 0 ? 9 : (GEO == 1 ? 1 : 4);
   static constexpr int PH = GEO == 0 ? R + 2 : (GEO == 1 ? R : 2 * R);
   static constexpr int PW = GEO == 0 ? 18 : (GEO == 1 ? 16 : 32);
@@ -51,12 +53,13 @@ __device__ __forceinline__ int tap_pixel(int geo, int tap, int r, int x) {
 }
 
 template <typename T, int GEO, int WC, int WI>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(const WgradArgs a) {
-  using G = WG<T, GEO>;
+__global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(const WgradArgs a) {
+  using G = WG<T, GEO, WC>;
   using E = ET<T>;
+  constexpr int NT = (WC * WI > 4 ? WC * WI : 4) * 64;      // threads: four waves, or one per 32 x 32 block (4 x 2 tiles)
   constexpr int R = G::R, NTAPS = G::NTAPS, BLKP = G::BLKP, PPB = G::PPB;
   constexpr int DZ_PIECES = G::NDZ * WC * PPB, PA_PIECES = G::NPP * WI * PPB;
-  constexpr int NDL = (DZ_PIECES + 255) / 256, NPL = (PA_PIECES + 255) / 256;
+  constexpr int NDL = (DZ_PIECES + NT - 1) / NT, NPL = (PA_PIECES + NT - 1) / NT;
   constexpr int DZ_BYTES = WC * G::NDZ * BLKP;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,18 +82,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
   const bool pro = (a.scale != nullptr);
   const int FH = GEO == 2 ? 2 * H : H, FW = GEO == 2 ? 2 * W : W;   // grid of the shifted operand
 
-  // tile-invariant piece decomposition: 256 % (W?*PPB) == 0, so a thread's channel slot is fixed
-  static_assert(256 % (WC * PPB) == 0 && 256 % (WI * PPB) == 0, "channel slot must be thread-invariant");
+  // tile-invariant piece decomposition: NT % (W?*PPB) == 0, so a thread's channel slot is fixed
+  static_assert(NT % (WC * PPB) == 0 && NT % (WI * PPB) == 0, "channel slot must be thread-invariant");
   const int dcc = tid % (WC * PPB), pcc = tid % (WI * PPB);
   int d_pix[NDL], p_pix[NPL];
 #pragma unroll
   for (int i = 0; i < NDL; ++i) {
-    const int q = tid + i * 256;
+    const int q = tid + i * NT;
     d_pix[i] = q < DZ_PIECES ? q / (WC * PPB) : -1;
   }
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
-    const int q = tid + i * 256;
+    const int q = tid + i * NT;
     p_pix[i] = q < PA_PIECES ? q / (WI * PPB) : -1;
   }
   float psc[E::VEC], psh[E::VEC];
@@ -185,6 +188,37 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
         const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
         const int gsub = g & 1, h = g >> 1;
         const int coff = (16 * gsub + 4 * p) * 2;
+        if constexpr (GEO == 2) {
+          // ConvTranspose: few MFMAs per tile (4 rows x 4 taps), so an LDS round trip in front of every MFMA is most of the
+          // tile's time: all dz fragments first, then the four tap fragments of row r+1 are read under the MFMAs of row r
+          typedef __attribute__((address_space(3))) s16x4* lds_v4;
+          const int xa = 8 * h + q;
+          bf16x8 fa[R], fb[2][NTAPS];
+          auto rd_b = [&](int r, bf16x8 (&F)[NTAPS]) {
+#pragma unroll
+            for (int tp = 0; tp < NTAPS; ++tp) {
+              const int p0 = tap_pixel(GEO, tp, r, xa), p1 = tap_pixel(GEO, tp, r, xa + 4);
+              const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pab + p0 * BLKP + coff));
+              const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pab + p1 * BLKP + coff));
+              F[tp] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+          };
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(dzb + (r * 16 + xa) * BLKP + coff));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(dzb + (r * 16 + xa + 4) * BLKP + coff));
+            fa[r] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+          rd_b(0, fb[0]);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (r + 1 < R) rd_b(r + 1, fb[(r + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tp = 0; tp < NTAPS; ++tp) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r], fb[r & 1][tp], acc[tp], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
       #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int xa = 8 * h + q;   // pixel column of read 0; read 1 is +4
@@ -200,6 +234,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
             const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
             acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tp], 0, 0, 0);
           }
+        }
         }
       } else {
         const int i32 = lane & 31, h = lane >> 5;
@@ -490,7 +525,7 @@ int launch_dma_pro(const WgradArgs& a, hipStream_t st) {
 
 template <typename T, int GEO, int WC, int WI>
 int launch_cfg(const WgradArgs& a, hipStream_t st) {
-  using G = WG<T, GEO>;
+  using G = WG<T, GEO, WC>;
   const size_t lds = (size_t)WC * G::NDZ * G::BLKP + (size_t)WI * G::NPP * G::BLKP;
   const int NCT = (a.CD / (32 * WC)) * ((a.CA + a.CB) / (32 * WI));
   auto kern = wgrad_kernel<T, GEO, WC, WI>;
@@ -501,7 +536,7 @@ int launch_cfg(const WgradArgs& a, hipStream_t st) {
       SEGK_FAIL(-3, "wgrad: cannot raise dynamic LDS limit");
     attr_set[dev_] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3((WC * WI > 4 ? WC * WI : 4) * 64), lds, st, a);
   SEGK_CHECK_LAUNCH("wgrad");
   return 0;
 }
@@ -518,6 +553,9 @@ int launch_geo(const WgradArgs& a, hipStream_t st) {
       if (wi2) return launch_dma_pro<1, 2>(a, st);
       return launch_dma_pro<1, 1>(a, st);
     }
+  }
+  if constexpr (GEO == 2 && sizeof(T) == 2) {     // ConvTranspose: 128 x 64 tiles halve the operand re-reads (it is traffic-bound)
+    if (segk_wgrad_wc(a.CD, a.CA, a.CB, 2, SEGK_DT_BF16) == 4) return launch_cfg<T, GEO, 4, 2>(a, st);
   }
   if (wc2 && wi2) return launch_cfg<T, GEO, 2, 2>(a, st);
   if (wc2) return launch_cfg<T, GEO, 2, 1>(a, st);
@@ -537,7 +575,7 @@ int launch_t(const WgradArgs& a, int geo, hipStream_t st) {
 // 32-channel blocks of the dz operand per workgroup (the host sizes the split-K slabs with it: segk_wgrad_split)
 int segk_wgrad_wc(int CD, int CA, int CB, int geo, int dtype) {
   static const bool off = getenv("SEGK_WGRAD_NO_WC4") != nullptr;      // A/B switch for tools/kbench.py
-  if (geo == 0 && dtype == SEGK_DT_BF16 && !off && CD % 128 == 0 && CA % 64 == 0 && CB % 64 == 0) return 4;
+  if ((geo == 0 || geo == 2) && dtype == SEGK_DT_BF16 && !off && CD % 128 == 0 && CA % 64 == 0 && CB % 64 == 0) return 4;
   return CD % 64 == 0 ? 2 : 1;
 }
 // split-K factor over spatial tiles: enough workgroups to fill the chip (two 4-wave workgroups or one 8-wave workgroup
@@ -547,7 +585,9 @@ int segk_wgrad_split(int tiles, int CD, int CA, int CB, int geo, int dtype) {
   const int wc = segk_wgrad_wc(CD, CA, CB, geo, dtype);
   const int wi = (CA % 64 == 0 && CB % 64 == 0) ? 2 : 1;
   const int nct = (CD / (32 * wc)) * ((CA + CB) / (32 * wi));
-  const int target = wc == 4 ? 256 : 512;
+  const int target = wc == 4 ? 256 : 512;     // a 4 x 2 workgroup (eight waves) fills a CU
+  if (wc == 4 && geo == 2) tiles = (tiles + 1) / 2;         // its ConvTranspose tiles are 8 rows (segk_wgrad_tiles counts 4-row tiles);
+                                                            // a slab whose index exceeds the tile count is written as zeros
   int S = nct < target ? target / nct : 1;
   if (S > tiles) S = tiles;
   return S < 1 ? 1 : S;

@@ -380,6 +380,27 @@ def test_convt2x2_forward_and_data_gradient(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 128, 64, 16, 16), (1, 256, 128, 6, 20), (3, 128, 64, 9, 7), (2, 64, 32, 8, 8),
+                                  (1, 96, 64, 5, 18), (2, 64, 128, 3, 33)])
+def test_convt2x2_weight_gradient(ops, dtype, case):
+    """ConvTranspose2d(k=2,s=2) weight gradient (wgrad geometry 2, reference unet/unet.py:59) against autograd: the
+    128 x 64 workgroup tiles with 8-row pixel tiles (bf16, Cin % 128 == 0, Cout % 64 == 0) and the smaller configurations,
+    heights and widths that are not multiples of the tile (rows past the image contribute zeros)."""
+    B, Cin, Cout, H, W = case
+    x0 = fill((B, Cin, H, W), 1, -1, 1).to(dtype).float()
+    w0 = (fill((Cin, Cout, 2, 2), 2, -1, 1) / Cin ** 0.5)
+    g0 = fill((B, Cout, 2 * H, 2 * W), 4, -1, 1).to(dtype).float()
+    w = w0.clone().requires_grad_(True)
+    F.conv_transpose2d(x0, w, None, stride=2).backward(g0)
+    xa = ops.to_act(dev(x0), dtype); px, Cinp = ops.act_info(xa, dtype)
+    ga = ops.to_act(dev(g0), dtype); pg, Coutp = ops.act_info(ga, dtype)
+    slabs, S = ops.wgrad(px, Cinp, pg, Coutp, 0, 0, B, H, W, 2, dtype, "cuda")
+    dw = ops.wgrad_to_param(slabs, S, w0.shape, Cin, Cout, 0, 4, "cuda").cpu()
+    # the operands are exactly representable in `dtype` and accumulate in fp32: only the summation order differs
+    assert (dw - w.grad).abs().max() <= 1e-4 * np.sqrt(B * H * W), case
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(64, 3, 0), (8, 3, 0), (64, 64, 0), (128, 64, 64), (70, 40, 0), (32, 20, 50)])
 def test_pack_both_layouts_matches_single_packs(ops, dtype, case):
     """The one-pass forward + data-gradient pack (segk_pack_conv3x3_both) against the per-mode pack, bit for bit."""

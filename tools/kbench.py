@@ -67,6 +67,10 @@ def main():
                 t = st[:2 * n].view(torch.int64).view(-1, 8, 8).double().cpu()       # [workgroup][wave][8]
                 tot = t[:, :, 6].clamp(min=1)
                 names = ["barrier wait", "MFMA loop", "DMA issue", "wait next tile", "epilogue", "loop tail/transform"]
+                if cin >= 128:
+                    # conv3x3_pipe_kernel (waves 0-3 consumers, 4-7 producers)
+                    names = ["step work (MFMA | staging)", "step barrier wait", "stage tile | E1 wait", "store tile",
+                             "E2..E3 (refill)", "prologue"]
                 print(f"      stamps over {t.shape[0]} workgroups: kernel {tot.mean():.0f} cycles per wave (min {tot.min():.0f} max {tot.max():.0f})")
                 for i, nm in enumerate(names):
                     sh = (t[:, :, i] / tot)

@@ -6,13 +6,14 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/image_segmentation_amd/csrc
 mkdir -p $R/tools/ubench/bin/stamp_obj
 for f in api conv_igemm conv_rs wgrad bn_pool pack head_loss resize vit gemm; do
-  if [ "$f" = conv_rs ]; then X="-DSEGK_RS_STAMPS ${RS_ABL:+-DRS_ABL=$RS_ABL} ${RS_EXTRA}"; else X=""; fi
-  if [ "$f" = conv_rs ] || [ ! -f $C/$f.o ]; then
+  if [ "$f" = conv_rs ]; then X="-DSEGK_RS_STAMPS ${RS_ABL:+-DRS_ABL=$RS_ABL} ${RS_EXTRA}";
+  elif [ "$f" = conv_igemm ]; then X="-DSEGK_PIPE_STAMPS ${PIPE_EXTRA}"; else X=""; fi
+  if [ "$f" = conv_rs ] || [ "$f" = conv_igemm ] || [ ! -f $C/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off $X -c $C/$f.hip -o $R/tools/ubench/bin/stamp_obj/$f.o
   else
     cp $C/$f.o $R/tools/ubench/bin/stamp_obj/$f.o
   fi
 done
-OUT=$R/tools/ubench/bin/libsegk_stamp${RS_ABL:+_abl$RS_ABL}${RS_TAG}.so
+OUT=$R/tools/ubench/bin/libsegk_stamp${RS_ABL:+_abl$RS_ABL}${RS_TAG}.so   # RS_TAG also names PIPE_EXTRA builds
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $R/tools/ubench/bin/stamp_obj/*.o
 echo built $OUT
