@@ -61,6 +61,8 @@ SIGNATURES = {
     "segk_resize_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_crop_resize": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_head_fwd": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_head_fwd_bn": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_head_bwd_bn": (_i, [_fp, _vp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _vp]),
     "segk_head_part_floats": (_i, [_l, _i]),
     "segk_head_bwd": (_i, [_fp, _vp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_head_bwd_blocks": (_i, [_l]),

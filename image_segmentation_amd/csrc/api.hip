@@ -26,9 +26,10 @@ int segk_pack_convt_weight_impl(const float*, void*, int, int, int, int, int, in
 int segk_pack_conv3x3_both_impl(const float*, void*, void*, int, int, int, int, int, int, int, hipStream_t);
 int segk_pack_conv3x3_multi_impl(const void*, int, int, int, hipStream_t);
 int segk_wgrad_reduce_impl(const float*, int, float*, int, int, int, int, int, int, int, hipStream_t);
-int segk_head_fwd_impl(const void*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int segk_head_fwd_impl(const void*, const float*, const float*, float*, int, int, int, int, int, int, const float*, const float*,
+                       int, hipStream_t);
 int segk_head_bwd_impl(const float*, const void*, const float*, void*, float*, float*, float*, int, int, int, int, int,
-                       int, const float*, const float*, const float*, const float*, float*, int, hipStream_t);
+                       int, const float*, const float*, const float*, const float*, float*, int, int, hipStream_t);
 int segk_head_blocks_q(long);
 int segk_loss_fwd_impl(const float*, const long long*, const float*, int, int, long, int, float, float, float, float*,
                        float*, int, int, float, hipStream_t);
@@ -250,13 +251,18 @@ int segk_bn_relu_bwd_from_part(const void* dy, const void* z, void* dz, const fl
 int segk_head_fwd(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp, int C,
                   int ncls, int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "head_fwd: bad dtype %d", dtype);
-  return segk_head_fwd_impl(y, w, bias, logits, B, H, W, Cp, C, ncls, dtype, (hipStream_t)s);
+  return segk_head_fwd_impl(y, w, bias, logits, B, H, W, Cp, C, ncls, nullptr, nullptr, dtype, (hipStream_t)s);
+}
+int segk_head_fwd_bn(const void* z, const float* scale, const float* shift, const float* w, const float* bias, float* logits,
+                     int B, int H, int W, int Cp, int C, int ncls, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(scale && shift, "head_fwd_bn: null scale/shift");
+  return segk_head_fwd_impl(z, w, bias, logits, B, H, W, Cp, C, ncls, scale, shift, dtype, (hipStream_t)s);
 }
 int segk_head_bwd(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
                   int B, int H, int W, int Cp, int C, int ncls, int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "head_bwd: bad dtype %d", dtype);
   return segk_head_bwd_impl(dlogits, y, w, dy, part, dw, db, B, H, W, Cp, C, ncls, nullptr, nullptr, nullptr, nullptr, nullptr,
-                            dtype, (hipStream_t)s);
+                            0, dtype, (hipStream_t)s);
 }
 int segk_head_bwd_blocks(long P) { return segk_head_blocks_q(P); }
 int segk_head_bwd_bnstat(const float* dlogits, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
@@ -264,7 +270,14 @@ int segk_head_bwd_bnstat(const float* dlogits, const void* y, const float* w, vo
                          const float* mean, const float* rstd, float* bnpart, int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "head_bwd_bnstat: bad dtype %d", dtype);
   SEGK_REQUIRE(bnpart, "head_bwd_bnstat: null partials");
-  return segk_head_bwd_impl(dlogits, y, w, dy, part, dw, db, B, H, W, Cp, C, ncls, scale, shift, mean, rstd, bnpart, dtype,
+  return segk_head_bwd_impl(dlogits, y, w, dy, part, dw, db, B, H, W, Cp, C, ncls, scale, shift, mean, rstd, bnpart, 0, dtype,
+                            (hipStream_t)s);
+}
+int segk_head_bwd_bn(const float* dlogits, const void* z, const float* w, void* dy, float* part, float* dw, float* db,
+                     int B, int H, int W, int Cp, int C, int ncls, const float* scale, const float* shift,
+                     const float* mean, const float* rstd, float* bnpart, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(scale && shift && mean && rstd, "head_bwd_bn: null BatchNorm vectors");
+  return segk_head_bwd_impl(dlogits, z, w, dy, part, dw, db, B, H, W, Cp, C, ncls, scale, shift, mean, rstd, bnpart, 1, dtype,
                             (hipStream_t)s);
 }
 int segk_loss_fwd(const float* logits, const int64_t* labels, const float* cw, int N, int C, long HW, int ignore_index,

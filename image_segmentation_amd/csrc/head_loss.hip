@@ -25,11 +25,15 @@ constexpr int HCH = 64;    // channels staged per pass
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ logits,
-                                                       long P, long HW, int Cp, int C, int ncls) {
+                                                       long P, long HW, int Cp, int C, int ncls,
+                                                       const float* __restrict__ zsc, const float* __restrict__ zsh) {
+  // zsc != NULL: the input is the pre-activation z of the last DoubleConv block and y = relu(z * zsc + zsh), rounded to T
+  // as segk_bn_relu_apply would have stored it, is formed on the way into LDS (the block's output is never written)
   using E = ET<T>;
   constexpr int PITCH = HCH * E::ES + 16;
   extern __shared__ __attribute__((aligned(16))) char tile[];   // HT * PITCH bytes
-  __shared__ float ws[MAXC * HCH];
+  __shared__ float ws[MAXC * HCH + 2 * HCH];
+  float* const zs = ws + MAXC * HCH;                            // [2][HCH] scale, shift of this pass
   const int tid = threadIdx.x;
   for (long p0 = (long)blockIdx.x * HT; p0 < P; p0 += (long)gridDim.x * HT) {
     float acc[NC];
@@ -38,10 +42,26 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
     for (int c0 = 0; c0 < Cp; c0 += HCH) {
       __syncthreads();
       constexpr int VPR = HCH / E::VEC;  // 16-byte vectors per pixel row of this pass
+      if (zsc != nullptr) {
+        if (tid < 2 * HCH) {
+          const int c = c0 + (tid & (HCH - 1));
+          zs[tid] = c < Cp ? (tid < HCH ? zsc[c] : zsh[c]) : 0.f;
+        }
+        __syncthreads();
+      }
       for (int q = tid; q < HT * VPR; q += 256) {
         const int px = q / VPR, v = q - px * VPR;
         uint4 d = make_uint4(0, 0, 0, 0);
-        if (p0 + px < P && c0 + v * E::VEC < Cp) d = *(const uint4*)(y + (size_t)(p0 + px) * Cp + c0 + v * E::VEC);
+        if (p0 + px < P && c0 + v * E::VEC < Cp) {
+          d = *(const uint4*)(y + (size_t)(p0 + px) * Cp + c0 + v * E::VEC);
+          if (zsc != nullptr) {
+            float f[E::VEC];
+            unpack16<T>(d, f);
+#pragma unroll
+            for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], zs[v * E::VEC + j], zs[HCH + v * E::VEC + j]), 0.f);
+            d = pack16<T>(f);
+          }
+        }
         *(uint4*)(tile + px * PITCH + v * 16) = d;
       }
       for (int q = tid; q < MAXC * HCH; q += 256) {
@@ -72,7 +92,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
 // dy[p][c] = sum_k dl[p][k] * W[k][c];  partial dW[k][c] = sum_p dl[p][k]*y[p][c], db[k] = sum_p dl[p][k].
 // Pure streaming: a thread owns one 16-byte channel vector (its weights W[k][c..c+VEC) and its dW partials
 // live in registers) and walks pixels; a row of threads covers whole contiguous pixel rows of y / dy.
-template <typename T, int NC>
+// ZIN: `y` holds the pre-activation z of the last DoubleConv block: y = relu(z * scale + shift) is re-formed per value
+// (rounded to T like the stored tensor would be) and the BatchNorm reductions take xhat = (z - mean) * rstd from z itself.
+template <typename T, int NC, bool ZIN>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlog, const T* __restrict__ y,
                                                        const float* __restrict__ w, T* __restrict__ dy,
                                                        float* __restrict__ part, long P, long HW, int Cp, int C,
@@ -104,23 +126,31 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       aw[k][j] = 0.f;
     }
   }
-  if (active && stat) {
+  float zc[ZIN ? E::VEC : 1], zh[ZIN ? E::VEC : 1];     // ZIN: scale, shift (xa = rstd, xb = -mean * rstd)
+  if (active && (stat || ZIN)) {
 #pragma unroll
     for (int j = 0; j < E::VEC; ++j) {
       const int c = cv * E::VEC + j;
       const float sc = bn_scale[c], rs = bn_rstd[c];
-      xa[j] = sc != 0.f ? rs / sc : 0.f;
-      xb[j] = -bn_shift[c] * xa[j] - bn_mean[c] * rs;
+      if constexpr (ZIN) {
+        zc[j] = sc; zh[j] = bn_shift[c];
+        xa[j] = rs; xb[j] = -bn_mean[c] * rs;
+      } else {
+        xa[j] = sc != 0.f ? rs / sc : 0.f;
+        xb[j] = -bn_shift[c] * xa[j] - bn_mean[c] * rs;
+      }
     }
   }
   if (active) {
-    for (long p = (long)blockIdx.x * rows + ry; p < P; p += (long)gridDim.x * rows) {
-      const long b = p / HW, r = p - b * HW;
-      float dl[NC];
+    // one pixel: dy, the dW / db partials and (stat) the BatchNorm reductions from the raw input vector `raw`
+    auto pixel = [&](long p, const float (&dl)[NC], const uint4 raw) {
+      float f[E::VEC], z[E::VEC], o[E::VEC];
+      unpack16<T>(raw, f);
+      if constexpr (ZIN) {
 #pragma unroll
-      for (int k = 0; k < NC; ++k) dl[k] = (k < ncls) ? dlog[(b * ncls + k) * HW + r] : 0.f;
-      float f[E::VEC], o[E::VEC];
-      unpack16<T>(*(const uint4*)(y + (size_t)p * Cp + cv * E::VEC), f);
+        for (int j = 0; j < E::VEC; ++j) { z[j] = f[j]; f[j] = fmaxf(fmaf(f[j], zc[j], zh[j]), 0.f); }
+        unpack16<T>(pack16<T>(f), f);               // the value segk_bn_relu_apply would have stored
+      }
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) o[j] = 0.f;
 #pragma unroll
@@ -138,9 +168,32 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         for (int j = 0; j < E::VEC; ++j) {
           const float gg = f[j] > 0.f ? o[j] : 0.f;
           sg[j] += gg;
-          sgx[j] = fmaf(gg, fmaf(f[j], xa[j], xb[j]), sgx[j]);
+          sgx[j] = fmaf(gg, fmaf(ZIN ? z[j] : f[j], xa[j], xb[j]), sgx[j]);
         }
       }
+    };
+    auto load_dl = [&](long p, float (&dl)[NC]) {
+      const long b = p / HW, r = p - b * HW;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) dl[k] = (k < ncls) ? dlog[(b * ncls + k) * HW + r] : 0.f;
+    };
+    // two pixels per iteration: both loads are in flight before either is used (the loop is latency-bound otherwise)
+    const long step = (long)gridDim.x * rows;
+    long p = (long)blockIdx.x * rows + ry;
+    for (; p + step < P; p += 2 * step) {
+      float dl0[NC], dl1[NC];
+      const uint4 r0 = *(const uint4*)(y + (size_t)p * Cp + cv * E::VEC);
+      const uint4 r1 = *(const uint4*)(y + (size_t)(p + step) * Cp + cv * E::VEC);
+      load_dl(p, dl0);
+      load_dl(p + step, dl1);
+      pixel(p, dl0, r0);
+      pixel(p + step, dl1, r1);
+    }
+    if (p < P) {
+      float dl0[NC];
+      const uint4 r0 = *(const uint4*)(y + (size_t)p * Cp + cv * E::VEC);
+      load_dl(p, dl0);
+      pixel(p, dl0, r0);
     }
   }
   if (ry < rows) {
@@ -431,8 +484,10 @@ int segk_head_part_floats(long P, int Cp) {
 }
 
 int segk_head_fwd_impl(const void* y, const float* w, const float* bias, float* logits, int B, int H, int W, int Cp,
-                       int C, int ncls, int dtype, hipStream_t st) {
+                       int C, int ncls, const float* zsc, const float* zsh, int dtype, hipStream_t st) {
   SEGK_REQUIRE(y && w && bias && logits && B > 0 && H > 0 && W > 0, "head_fwd: bad arguments");
+  SEGK_REQUIRE((zsc == nullptr) == (zsh == nullptr), "head_fwd: scale and shift come together");
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "head_fwd: bad dtype %d", dtype);
   SEGK_REQUIRE(ncls >= 1 && ncls <= MAXC, "head_fwd: 1..%d classes supported, got %d", MAXC, ncls);
   SEGK_REQUIRE(Cp % 32 == 0 && C > 0 && C <= Cp, "head_fwd: bad channels");
   const long P = (long)B * H * W, HW = (long)H * W;
@@ -444,7 +499,8 @@ int segk_head_fwd_impl(const void* y, const float* w, const float* bias, float* 
     constexpr int NC = decltype(NCc)::value;
     auto kern = head_fwd_kernel<T, NC>;
     if (!raise_lds((const void*)kern)) return false;
-    hipLaunchKernelGGL(kern, dim3((int)g), dim3(256), head_lds<T>(), st, (const T*)y, w, bias, logits, P, HW, Cp, C, ncls);
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(256), head_lds<T>(), st, (const T*)y, w, bias, logits, P, HW, Cp, C, ncls, zsc,
+                       zsh);
     return true;
   };
   auto by_nc = [&](auto Tc) {
@@ -461,7 +517,8 @@ int segk_head_fwd_impl(const void* y, const float* w, const float* bias, float* 
 
 template <typename T>
 static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
-                      long P, long HW, int Cp, int C, int ncls, const float* const* bn, float* bnpart, hipStream_t st) {
+                      long P, long HW, int Cp, int C, int ncls, const float* const* bn, float* bnpart, bool zin,
+                      hipStream_t st) {
   using E = ET<T>;
   const int cvec = Cp / E::VEC;
   const int cvb = cvec < 64 ? cvec : 64;
@@ -469,14 +526,15 @@ static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy
   const int nb = segk_head_blocks(P);
   const size_t lds = (size_t)rows * cvb * (MAXC * E::VEC + MAXC) * sizeof(float);
   SEGK_REQUIRE(gy == 1, "head_bwd: at most %d input channels supported", 64 * E::VEC);
-  auto launch = [&](auto NCc) {
+  auto launch_z = [&](auto NCc, auto ZINc) {
     constexpr int NC = decltype(NCc)::value;
-    auto kern = head_bwd_kernel<T, NC>;
+    auto kern = head_bwd_kernel<T, NC, decltype(ZINc)::value>;
     if (!raise_lds((const void*)kern)) return false;
     hipLaunchKernelGGL(kern, dim3(nb, gy), dim3(256), lds, st, dlog, (const T*)y, w, (T*)dy, part, P, HW, Cp, C, ncls, cvb, rows,
                        bn ? bn[0] : nullptr, bn ? bn[1] : nullptr, bn ? bn[2] : nullptr, bn ? bn[3] : nullptr, bnpart);
     return true;
   };
+  auto launch = [&](auto NCc) { return zin ? launch_z(NCc, std::true_type{}) : launch_z(NCc, std::false_type{}); };
   const bool ok = ncls <= 2 ? launch(std::integral_constant<int, 2>{})
                 : ncls == 3 ? launch(std::integral_constant<int, 3>{})
                 : ncls == 4 ? launch(std::integral_constant<int, 4>{})
@@ -490,15 +548,17 @@ static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy
 
 int segk_head_bwd_impl(const float* dlog, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
                        int B, int H, int W, int Cp, int C, int ncls, const float* bn_scale, const float* bn_shift,
-                       const float* bn_mean, const float* bn_rstd, float* bnpart, int dtype, hipStream_t st) {
+                       const float* bn_mean, const float* bn_rstd, float* bnpart, int zin, int dtype, hipStream_t st) {
   SEGK_REQUIRE(dlog && y && w && dy && part && dw && db && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
   SEGK_REQUIRE(ncls >= 1 && ncls <= MAXC && Cp % 32 == 0 && C > 0 && C <= Cp, "head_bwd: bad channels/classes");
-  SEGK_REQUIRE(!bnpart || (bn_scale && bn_shift && bn_mean && bn_rstd), "head_bwd: BatchNorm reductions need scale/shift/mean/rstd");
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "head_bwd: bad dtype %d", dtype);
+  SEGK_REQUIRE(!(bnpart || zin) || (bn_scale && bn_shift && bn_mean && bn_rstd),
+               "head_bwd: BatchNorm reductions / a pre-activation input need scale, shift, mean and rstd");
   const long P = (long)B * H * W, HW = (long)H * W;
   const float* bn[4] = {bn_scale, bn_shift, bn_mean, bn_rstd};
-  const float* const* bnp = bnpart ? bn : nullptr;
-  return dtype == SEGK_DT_BF16 ? head_bwd_t<bf16_t>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, bnp, bnpart, st)
-                               : head_bwd_t<float>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, bnp, bnpart, st);
+  const float* const* bnp = (bnpart || zin) ? bn : nullptr;
+  return dtype == SEGK_DT_BF16 ? head_bwd_t<bf16_t>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, bnp, bnpart, zin != 0, st)
+                               : head_bwd_t<float>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, bnp, bnpart, zin != 0, st);
 }
 int segk_head_blocks_q(long P) { return segk_head_blocks(P); }
 

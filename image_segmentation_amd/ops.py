@@ -8,6 +8,8 @@ backed by an NHWC buffer [B,H,W,Cp] with Cp = C rounded up to 32 and zero paddin
 dtype (fp32 = parity mode, bf16 = performance mode).  For C % 32 == 0 this is exactly torch's
 channels_last memory format.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -127,6 +129,8 @@ def _raw(t, dtype):
 # enough: fused optimizers (torch.optim.AdamW(fused=True), torch._fused_adamw_) update parameters in place WITHOUT
 # moving `param._version`, so a global post-step hook counts optimizer steps as well.
 FUSE_BN_REDUCE = True    # pooling / head backward also accumulate the producing block's BN2 backward reductions
+# a block followed by the output head hands it the pre-activation: BN+ReLU happen inside the head kernels
+HEAD_ON_Z = os.environ.get("SEGK_HEAD_ON_Z", "1") != "0"       # the env switch is for same-box A/B runs of bench.py
 _OPT_EPOCH = [0]
 
 
@@ -555,22 +559,28 @@ def _convt_bwd(mod, x_t, w, pd, B, H, W, Cin, Cout, dtype, dev, need_dx, has_bia
     return dx, dw, db
 
 
-def _head_fwd(px, Cp, w, b, B, C, H, W, dtype, dev):
+def _head_fwd(px, Cp, w, b, B, C, H, W, dtype, dev, bn=None):
+    """bn = (scale, shift): px points at the block's PRE-ACTIVATION z and the kernel forms relu(z*scale+shift) itself
+    (HEAD_ON_Z: the block output is never written)."""
     ncls = w.shape[0]
     if ncls > _lib.MAX_CLASSES:
         raise RuntimeError(f"output head supports up to {_lib.MAX_CLASSES} classes, got {ncls}")
     w2 = _param_f32(w).reshape(ncls, C)
     logits = torch.empty((B, ncls, H, W), dtype=torch.float32, device=dev)
     with _span("head_fwd", 2.0 * B * H * W * C * ncls, B * H * W * (C * _es(dtype) + 4 * ncls)):
-        _lib.call("segk_head_fwd", px, w2.data_ptr(), _param_f32(b).data_ptr(), logits.data_ptr(), B, H, W, Cp, C,
-                  ncls, _DT[dtype], _stream())
+        if bn is not None:
+            _lib.call("segk_head_fwd_bn", px, bn[0].data_ptr(), bn[1].data_ptr(), w2.data_ptr(), _param_f32(b).data_ptr(),
+                      logits.data_ptr(), B, H, W, Cp, C, ncls, _DT[dtype], _stream())
+        else:
+            _lib.call("segk_head_fwd", px, w2.data_ptr(), _param_f32(b).data_ptr(), logits.data_ptr(), B, H, W, Cp, C,
+                      ncls, _DT[dtype], _stream())
     return logits
 
 
-def _head_bwd(dlogits, px, Cp, w, B, C, H, W, dtype, dev, bn=None):
+def _head_bwd(dlogits, px, Cp, w, B, C, H, W, dtype, dev, bn=None, on_z=False):
     """-> (dy NHWC buffer, dw, db, bn_ready).  bn = (scale, shift, mean, rstd) of the BatchNorm whose output y the head
     reads: the kernel then also accumulates that BatchNorm's backward reductions over the dy it writes
-    (bn_ready = (partials, rows) for bn_relu_bwd)."""
+    (bn_ready = (partials, rows) for bn_relu_bwd).  on_z: px points at the pre-activation z (see _head_fwd)."""
     ncls = w.shape[0]
     dl = dlogits
     if dl.dtype != torch.float32 or not dl.is_contiguous():
@@ -582,7 +592,17 @@ def _head_bwd(dlogits, px, Cp, w, B, C, H, W, dtype, dev, bn=None):
     db = _f32(ncls, dev)
     ready = None
     with _span("head_bwd", 4.0 * B * H * W * C * ncls, B * H * W * (2 * C * _es(dtype) + 4 * ncls)):
-        if bn is not None and FUSE_BN_REDUCE:
+        if on_z:
+            sc, sh, mu, rs = bn
+            bnpart, nb = None, 0
+            if FUSE_BN_REDUCE:
+                nb = _lib.query("segk_head_bwd_blocks", B * H * W)
+                bnpart = _f32(nb * Cp * 2, dev)
+                ready = (bnpart, nb)
+            _lib.call("segk_head_bwd_bn", dl.data_ptr(), px, w2.data_ptr(), dy.data_ptr(), part.data_ptr(),
+                      dw.data_ptr(), db.data_ptr(), B, H, W, Cp, C, ncls, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
+                      rs.data_ptr(), _p(bnpart), _DT[dtype], _stream())
+        elif bn is not None and FUSE_BN_REDUCE:
             sc, sh, mu, rs = bn
             nb = _lib.query("segk_head_bwd_blocks", B * H * W)
             bnpart = _f32(nb * Cp * 2, dev)
@@ -691,9 +711,12 @@ class DoubleConvFn(torch.autograd.Function):
                                          training, dev)
         if training:
             _bump_batch_counters(bn1, bn2)
-        y = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
+        head_on_z = head_w is not None and HEAD_ON_Z
+        y = None if head_on_z else torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         pooled = None
-        if cfg.emit_pool:
+        if head_on_z:
+            pass         # the head kernels form relu(bn(z2)) themselves: the block output is never written
+        elif cfg.emit_pool:
             if H < 2 or W < 2:
                 raise RuntimeError("MaxPool2d(2,2): input smaller than the window")
             # this block's output feeds a Down block: BN+ReLU and its MaxPool2d(2,2) in one pass over z2
@@ -706,7 +729,9 @@ class DoubleConvFn(torch.autograd.Function):
                 _lib.call("segk_bn_relu_apply", z2.data_ptr(), y.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), P, Coutp,
                           _DT[dtype], _stream())
         logits = None
-        if head_w is not None:
+        if head_on_z:
+            logits = _head_fwd(z2.data_ptr(), Coutp, head_w, head_b, B, Cout, H, W, dtype, dev, bn=(sc2, sh2))
+        elif head_w is not None:
             logits = _head_fwd(y.data_ptr(), Coutp, head_w, head_b, B, Cout, H, W, dtype, dev)
 
         ctx.cfg, ctx.dtype, ctx.dims = cfg, dtype, (B, H, W, CA, CB, Cout)
@@ -714,6 +739,7 @@ class DoubleConvFn(torch.autograd.Function):
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.up_dims = up_dims
         ctx.has_head = head_w is not None
+        ctx.head_on_z = head_on_z
         ctx.save_for_backward(xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2, a1,
                               y if (cfg.emit_pool or head_w is not None) else None, up_t, up_w, head_w)
         if logits is not None:
@@ -743,8 +769,9 @@ class DoubleConvFn(torch.autograd.Function):
         d_head_w = d_head_b = None
         keep = None
         if ctx.has_head:
-            dy_buf, d_head_w, d_head_b, ready = _head_bwd(grads[0], y.data_ptr(), Coutp, head_w, B, Cout, H, W, dtype, dev,
-                                                          bn=(sc2, sh2, mu2, rs2))
+            src = z2 if ctx.head_on_z else y
+            dy_buf, d_head_w, d_head_b, ready = _head_bwd(grads[0], src.data_ptr(), Coutp, head_w, B, Cout, H, W, dtype, dev,
+                                                          bn=(sc2, sh2, mu2, rs2), on_z=ctx.head_on_z)
             pdy, keep = dy_buf.data_ptr(), dy_buf
         elif cfg.emit_pool:
             dy, dpool = grads

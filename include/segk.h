@@ -220,6 +220,16 @@ int segk_head_bwd_bnstat(const float* dlogits, const void* y, const float* w, vo
                          int B, int H, int W, int Cp, int C, int ncls, const float* scale, const float* shift,
                          const float* mean, const float* rstd, float* bnpart, int dtype, segk_stream_t s);
 
+/* The same head reading the block's PRE-ACTIVATION z instead of its output (unet.py:103-105: the output of up4 is
+ * consumed by the head alone, so relu(z * scale + shift) -- rounded to `dtype` exactly as segk_bn_relu_apply stores it --
+ * is re-formed inside both kernels and never written): forward, and backward writing the gradient of that (virtual)
+ * output to dy; bnpart (may be NULL) receives the BatchNorm backward reductions with xhat = (z - mean) * rstd. */
+int segk_head_fwd_bn(const void* z, const float* scale, const float* shift, const float* w, const float* bias, float* logits,
+                     int B, int H, int W, int Cp, int C, int ncls, int dtype, segk_stream_t s);
+int segk_head_bwd_bn(const float* dlogits, const void* z, const float* w, void* dy, float* part, float* dw, float* db,
+                     int B, int H, int W, int Cp, int C, int ncls, const float* scale, const float* shift,
+                     const float* mean, const float* rstd, float* bnpart, int dtype, segk_stream_t s);
+
 /* ---- per-pixel CrossEntropy + soft Dice (training.py:47; utils/weighted_loss.py:31-98,140-166) ----
  * logits NCHW fp32 [N,C,HW], labels int64 [N,HW].  state (segk_loss_state_floats() floats):
  * [0]=dice_weight*dice+ce_weight*ce, [1]=ce, [2]=dice, rest = saved statistics for backward.

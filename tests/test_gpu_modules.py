@@ -387,3 +387,35 @@ def test_one_launch_repack_after_optimizer_step(seg, dtype):
     l2 = loss_fn(m(X), Y); l2.backward()       # and the step after it runs on the refreshed copies
     assert torch.isfinite(l2)
     seg.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_head_on_preactivation_matches_head_on_block_output(seg, dtype):
+    """ops.HEAD_ON_Z: the last block hands the output head its pre-activation and the head kernels form relu(bn(z)) themselves
+    (segk_head_fwd_bn / segk_head_bwd_bn; the block output is never written).  The logits equal the two-kernel path bit for
+    bit (the re-formed value is rounded exactly as the stored one), the gradients agree to accumulation-order level in fp32
+    and to bf16 resolution in bf16 (there the unfused path recovers xhat from the ROUNDED output, this one takes it from z)."""
+    from image_segmentation_amd import ops
+    seg.set_compute_dtype(dtype)
+    X = fill((2, 3, 32, 48), 11, 0, 1).cuda(); Y = labels((2, 32, 48), 12, 3).cuda()
+    loss_fn = seg.CrossEntropyLoss()
+    out = {}
+    for flag in (False, True):
+        ops.HEAD_ON_Z = flag
+        try:
+            m = seg.unet(3, 3); fill_module(m, 500); m = m.cuda().train()
+            lg = m(X)
+            loss_fn(lg, Y).backward()
+            out[flag] = (lg.detach().clone(), {n: p.grad.float().clone() for n, p in m.named_parameters()})
+            m.eval()
+            with torch.no_grad():
+                out[(flag, "eval")] = m(X).clone()
+        finally:
+            ops.HEAD_ON_Z = True
+    assert torch.equal(out[False][0], out[True][0])
+    assert torch.equal(out[(False, "eval")], out[(True, "eval")])
+    rel = 2e-4 if dtype == torch.float32 else 2e-2
+    for n, a in out[True][1].items():
+        b = out[False][1][n]
+        assert (a - b).norm() <= rel * b.norm() + 1e-6, (n, (a - b).norm().item(), b.norm().item())
+    seg.set_compute_dtype(torch.bfloat16)
