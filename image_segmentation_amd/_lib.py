@@ -84,8 +84,10 @@ _lib = None
 def load():
     """Load libsegk.so (building nothing: run `python -m image_segmentation_amd.build` or
     __graft_entry__.build() first).  Raises if the library is absent -- there is no fallback path."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
+        if os.environ.get("SEGK_LIB"):       # diagnostic builds only (tools/stamp_build.sh, same-box A/B of two builds)
+            LIB_PATH = os.path.abspath(os.environ["SEGK_LIB"])
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU/eager fallback exists). "

@@ -7,11 +7,45 @@
 // clip/clipunet.py:88,91 (eps 1e-5, momentum 0.1, biased variance to normalise, unbiased variance into
 // running_var), nn.ReLU, nn.MaxPool2d(2,2) at unet.py:40 (backward routes to the first maximum in
 // row-major window order).
+#include <atomic>
 #include "common.hpp"
 #include "segk_internal.h"
 #include "../../include/segk.h"
 
 namespace {
+// ---------------------------------------------------------------------------------------------
+// In-launch hand-off from the blocks of one reduction to the block that finishes it (instead of a second, tiny kernel):
+// every block publishes its partials and draws a ticket; the block that draws the last one reads them all.  One counter
+// per (slot, group); a launch takes the next slot (host side, round robin), the finishing block resets its counter, so
+// a slot is clean again long before the ring of slots comes back to it.  Agent-scope release / acquire around a relaxed
+// ticket (cdna_hip_programming.md, in-launch split-K reduction): correct wherever the blocks run.
+constexpr int TICKET_SLOTS = 256, TICKET_GROUPS = 32;
+__device__ unsigned g_tickets[TICKET_SLOTS * TICKET_GROUPS];     // zero at module load
+inline int next_ticket_slot() {
+  static std::atomic<unsigned> n{0};
+  return (int)(n.fetch_add(1, std::memory_order_relaxed) % TICKET_SLOTS);
+}
+// true in every thread of the block that arrives LAST of `n` at `counter` (the caller's global stores are published
+// first; the last block may then read every other block's).  flag: one int of LDS nobody else touches across the call.
+__device__ __forceinline__ bool last_arriver(unsigned* counter, unsigned n, volatile int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == n - 1) ? 1 : 0;
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
 
 // block = CVB channel-vectors x ROWS pixel lanes (CVB*ROWS <= 256); grid.y covers channel blocks.
 struct Lanes {
@@ -30,9 +64,8 @@ __device__ __forceinline__ Lanes lanes(int cvb, int cvec) {
 // ---------------------------------------------------------------------------------------------
 constexpr int NCH = 32;   // first-stage chunks of the per-tile statistics reduction
 // stage A: per-tile partials [MT][C][2] float -> [NCH][C][2] double (fixed order inside a chunk: bit-stable)
-__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __restrict__ part, int MT, int C,
-                                                              double* __restrict__ out) {
-  __shared__ double sh[8][32][2];
+__device__ __forceinline__ void stats_chunk(const float* __restrict__ part, int MT, int C, double* __restrict__ out,
+                                            double (&sh)[8][32][2]) {
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   const int chunk = (MT + NCH - 1) / NCH;
@@ -54,14 +87,13 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __res
   }
 }
 
-// stage B: [NCH][C][2] double partials -> scale/shift (+ running stats)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int MT, int C, int C_real,
-                                                          double count, const float* conv_bias,
-                                                          const float* gamma, const float* beta, float* rmean,
-                                                          float* rvar, float momentum, float eps, int training,
-                                                          float* scale, float* shift, float* mean_out,
-                                                          float* rstd_out) {
-  __shared__ double sh[8][32][2];
+// stage B: [MT][C][2] double partials -> scale/shift (+ running stats) for the 32 channels of blockIdx.x
+__device__ __forceinline__ void finalize_channels(const double* __restrict__ part, int MT, int C, int C_real,
+                                                  double count, const float* conv_bias,
+                                                  const float* gamma, const float* beta, float* rmean,
+                                                  float* rvar, float momentum, float eps, int training,
+                                                  float* scale, float* shift, float* mean_out,
+                                                  float* rstd_out, double (&sh)[8][32][2]) {
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   double s1 = 0.0, s2 = 0.0;
@@ -105,6 +137,35 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     shift[c] = be + (cb - rmean[c]) * sc;
     if (mean_out) { mean_out[c] = rmean[c] - cb; rstd_out[c] = rstd; }
   }
+}
+
+// eval mode (no statistics to reduce): stage B alone
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int MT, int C, int C_real,
+                                                          double count, const float* conv_bias,
+                                                          const float* gamma, const float* beta, float* rmean,
+                                                          float* rvar, float momentum, float eps, int training,
+                                                          float* scale, float* shift, float* mean_out,
+                                                          float* rstd_out) {
+  __shared__ double sh[8][32][2];
+  finalize_channels(part, MT, C, C_real, count, conv_bias, gamma, beta, rmean, rvar, momentum, eps, training, scale, shift,
+                    mean_out, rstd_out, sh);
+}
+
+// training mode, ONE launch: grid (C/32, NCH) blocks reduce their chunk of the per-tile partials (stage A); the block that
+// arrives last for a channel group finishes it (stage B over the NCH chunk sums, in chunk order: bit-stable)
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int MT, int C, int C_real,
+                                                                double count, const float* conv_bias,
+                                                                const float* gamma, const float* beta, float* rmean,
+                                                                float* rvar, float momentum, float eps,
+                                                                float* scale, float* shift, float* mean_out,
+                                                                float* rstd_out, double* __restrict__ scratch,
+                                                                unsigned* __restrict__ tickets) {
+  __shared__ double sh[8][32][2];
+  __shared__ int last;
+  stats_chunk(part, MT, C, scratch, sh);
+  if (!last_arriver(tickets + blockIdx.x, gridDim.y, &last)) return;
+  finalize_channels(scratch, (int)gridDim.y, C, C_real, count, conv_bias, gamma, beta, rmean, rvar, momentum, eps, 1, scale,
+                    shift, mean_out, rstd_out, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -465,8 +526,16 @@ int segk_bn_finalize_impl(const float* part, int MT, int C, int C_real, double c
   // the stats buffer carries NCH*C*2 doubles of scratch behind the [MT][C][2] float partials
   double* scratch = part ? (double*)(const_cast<float*>(part) + (size_t)MT * C * 2) : nullptr;
   if (training) {
-    hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3(C / 32, NCH), dim3(256), 0, st, part, MT, C, scratch);
-    SEGK_CHECK_LAUNCH("bn_stats_reduce");
+    SEGK_REQUIRE(C / 32 <= TICKET_GROUPS, "bn_finalize: at most %d channels", 32 * TICKET_GROUPS);
+    static unsigned* ticket_base[SEGK_MAX_DEVICES] = {};      // per device: the symbol lives in that device's module image
+    const int dev = segk_device_index();
+    if (!ticket_base[dev] && hipGetSymbolAddress((void**)&ticket_base[dev], HIP_SYMBOL(g_tickets)) != hipSuccess)
+      SEGK_FAIL(-3, "bn_finalize: no ticket array");
+    unsigned* tickets = ticket_base[dev] + (size_t)next_ticket_slot() * TICKET_GROUPS;
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 32, NCH), dim3(256), 0, st, part, MT, C, C_real, count, conv_bias,
+                       gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean, rstd, scratch, tickets);
+    SEGK_CHECK_LAUNCH("bn_stats_finalize");
+    return 0;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 32), dim3(256), 0, st, scratch, NCH, C, C_real, count, conv_bias,
                      gamma, beta, rmean, rvar, momentum, eps, training, scale, shift, mean, rstd);

@@ -202,19 +202,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int i = threadIdx.x; i < K * taps; i += 256) dst[i] = row[i];
 }
 
-// stage 1 for large split-K factors: fold slab s into slab (s mod G), in place, float4-wide and fully parallel
-__global__ __launch_bounds__(256) void slab_fold_kernel(float* __restrict__ slabs, int S, int G, long slab_vec) {
-  const long total = slab_vec * G;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int g = (int)(i / slab_vec);
-    const long v = i - (long)g * slab_vec;
-    float4* p = (float4*)slabs + (long)g * slab_vec + v;
-    float4 acc = *p;
-    for (int t = g + G; t < S; t += G) {           // fixed order: bit-stable
-      const float4 x = ((const float4*)slabs)[(long)t * slab_vec + v];
+// The same sum for MANY thin slabs (narrow layers: split-K factors of 64 .. 512 over a gradient of a few hundred KB), in
+// one launch: a block owns 16 float4 vectors of one output row and walks the slabs in 16 interleaved streams
+// (thread = vector lane x slab lane), then adds the 16 stream sums in lane order (fixed order: bit-stable) and scatters the
+// 64 values to their [k][tap] places.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ slabs, int S,
+                                                                float* __restrict__ grad, int N, int CA, int CB, int Np,
+                                                                int CAp, int CBp, int taps) {
+  __shared__ float4 red[16][16];
+  const int Kp = CAp + CBp, K = CA + CB;
+  const int n = blockIdx.x;
+  const int vl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int nvec = taps * Kp / 4;
+  const int v = blockIdx.y * 16 + vl;
+  const long slab = (long)Np * taps * Kp;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (v < nvec) {
+    const float* base = slabs + (long)n * taps * Kp + (long)v * 4;
+    for (int t = sl; t < S; t += 16) {
+      const float4 x = *(const float4*)(base + (long)t * slab);
       acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
     }
-    *p = acc;
+  }
+  red[sl][vl] = acc;
+  __syncthreads();
+  if (sl != 0 || v >= nvec) return;
+#pragma unroll
+  for (int r = 1; r < 16; ++r) {
+    const float4 x = red[r][vl];
+    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+  }
+  const int e = v * 4, tap = e / Kp, kp = e - tap * Kp;
+  const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
+  float* dst = grad + (long)n * K * taps;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = kp + j;
+    const int k = q < CAp ? (q < CA ? q : -1) : (q - CAp < CB ? CA + q - CAp : -1);
+    if (k >= 0) dst[k * taps + tap] = vals[j];
   }
 }
 
@@ -314,13 +339,12 @@ int segk_wgrad_reduce_impl(const float* slabs, int S, float* grad, int N, int CA
                            int taps, hipStream_t st) {
   SEGK_REQUIRE(slabs && grad && S > 0 && N > 0 && CA > 0 && CB >= 0 && Np >= N && CAp >= CA && CBp >= CB && taps > 0,
                "wgrad_reduce: bad arguments");
-  constexpr int G = 8;
-  if (S > 2 * G) {   // many thin slabs (narrow layers): fold them to G slabs first so stage 2 stays parallel
-    const long slab_vec = (long)Np * taps * (CAp + CBp) / 4;
-    hipLaunchKernelGGL(slab_fold_kernel, dim3(grid_for(slab_vec * G)), dim3(256), 0, st, const_cast<float*>(slabs), S, G,
-                       slab_vec);
-    SEGK_CHECK_LAUNCH("slab_fold");
-    S = G;
+  if (S > 16) {      // many thin slabs (narrow layers): slab-parallel reduction, one launch
+    const int nvec = taps * (CAp + CBp) / 4;
+    hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(N, (nvec + 15) / 16), dim3(256), 0, st, slabs, S, grad, N, CA, CB, Np, CAp,
+                       CBp, taps);
+    SEGK_CHECK_LAUNCH("wgrad_reduce_wide");
+    return 0;
   }
   const size_t lds = (size_t)(CA + CB) * taps * sizeof(float);
   SEGK_REQUIRE(lds <= 64 * 1024, "wgrad_reduce: a gradient row of %zu bytes exceeds the LDS staging limit", lds);

@@ -93,7 +93,7 @@ int segk_convt2x2_dgrad(const void* dout, const void* wpacked, void* din, int B,
 /* ---- weight gradients ---------------------------------------------------------------------------
  * slabs [S][CD][taps][CA+CB] fp32 = split-K partials of  sum_p dz[p][n] * a[p+tap][k]; then
  * segk_wgrad_reduce sums them in fixed order into the reference-layout gradient (fp32, overwritten; the
- * slabs are scratch and may be folded in place).
+ * slabs are read only).
  * geo 0: Conv2d 3x3 (grad OIHW [N][CA+CB][9]);  geo 1: Conv2d 1x1;  geo 2: ConvTranspose2d(k=2,s=2) with
  * dz := layer input [B,H,W,CD], srcA := output gradient [B,2H,2W,CA], grad IOHW [CD][CA][2][2].
  * scale/shift: BatchNorm+ReLU prologue on srcA (the conv input is relu(bn(z)) of the previous conv). */
