@@ -23,7 +23,8 @@ SIGNATURES = {
     "segk_nhwc_to_nchw": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_pack_conv_weight": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_pack_conv3x3_both": (_i, [_fp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "segk_pack_conv3x3_multi": (_i, [_vp, _i, _i, _i, _vp]),
+    "segk_pack_multi": (_i, [_vp, _i, _i, _i, _vp]),
+    "segk_pack_convt_chunk": (_i, []),
     "segk_pack_convt_weight": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_conv_tiles": (_i, [_i, _i, _i, _i, _i, _i]),
     "segk_bn_stats_floats": (_i, [_i, _i]),

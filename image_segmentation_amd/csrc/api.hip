@@ -24,7 +24,8 @@ int segk_nhwc_to_nchw_impl(const void*, float*, int, int, int, int, int, int, hi
 int segk_pack_conv_weight_impl(const float*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int segk_pack_convt_weight_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
 int segk_pack_conv3x3_both_impl(const float*, void*, void*, int, int, int, int, int, int, int, hipStream_t);
-int segk_pack_conv3x3_multi_impl(const void*, int, int, int, hipStream_t);
+int segk_pack_multi_impl(const void*, int, int, int, hipStream_t);
+int segk_pack_convt_chunk_impl();
 int segk_wgrad_reduce_impl(const float*, int, float*, int, int, int, int, int, int, int, hipStream_t);
 int segk_head_fwd_impl(const void*, const float*, const float*, float*, int, int, int, int, int, int, const float*, const float*,
                        int, hipStream_t);
@@ -84,8 +85,9 @@ int segk_pack_conv3x3_both(const float* w, void* dst_fwd, void* dst_dgrad, int C
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "pack_conv3x3_both: bad dtype %d", dtype);
   return segk_pack_conv3x3_both_impl(w, dst_fwd, dst_dgrad, Cout, CA, CB, Coutp, CAp, CBp, dtype, (hipStream_t)s);
 }
-int segk_pack_conv3x3_multi(const void* table, int n, int total_blocks, int dtype, segk_stream_t s) {
-  return segk_pack_conv3x3_multi_impl(table, n, total_blocks, dtype, (hipStream_t)s);
+int segk_pack_convt_chunk(void) { return segk_pack_convt_chunk_impl(); }
+int segk_pack_multi(const void* table, int n, int total_blocks, int dtype, segk_stream_t s) {
+  return segk_pack_multi_impl(table, n, total_blocks, dtype, (hipStream_t)s);
 }
 int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cinp, int Coutp, int mode, int dtype,
                            segk_stream_t s) {

@@ -134,39 +134,64 @@ __global__ __launch_bounds__(256) void pack_conv3x3_both_kernel(const float* __r
   __shared__ float tile[32][32 * 9 + 1];
   pack_conv3x3_both_block<T>(w, df, dd, Cout, CA, CB, Coutp, CAp, CBp, blockIdx.x, blockIdx.y, tile);
 }
-// Every 3x3 weight of a model in ONE launch (segk_pack_conv3x3_multi): `table` lists the tensors, a block finds its
-// tensor by its first block index (entries sorted, <= 64 of them) and runs the same 32 x 32 x 9 tile routine.
-template <typename T>
-__global__ __launch_bounds__(256) void pack_conv3x3_multi_kernel(const SegkPackEntry* __restrict__ table, int n) {
-  __shared__ float tile[32][32 * 9 + 1];
-  int e = 0;
-  for (int i = 1; i < n; ++i) e = ((int)blockIdx.x >= table[i].block0) ? i : e;     // scalar loop (uniform)
-  const SegkPackEntry t = table[e];
-  const int lid = blockIdx.x - t.block0, gx = (t.CAp + t.CBp) / 32;
-  pack_conv3x3_both_block<T>(t.w, (T*)t.dst_fwd, (T*)t.dst_dgrad, t.Cout, t.CA, t.CB, t.Coutp, t.CAp, t.CBp, lid % gx, lid / gx,
-                             tile);
-}
-
 // ConvTranspose2d(k=2,s=2) weight [Cin][Cout][2][2] -> packed.
 //  mode 0 (forward GEMM, N = q*Coutp + co, K = ci):         dst[kc][0][n][j] = W[ci=kc*CH+j][co][q]
 //  mode 1 (data grad, K = q*Coutp + co via un-shuffle):     dst[kc][0][n=ci][j] = W[ci][co][q], kc = q*(Coutp/CH)+cc
 template <typename T>
+__device__ __forceinline__ T convt_packed_value(const float* __restrict__ w, long i, int Cin, int Cout, int Cinp, int Coutp,
+                                               int mode);
+template <typename T>
 __global__ void pack_convt_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cin, int Cout, int Cinp,
                                          int Coutp, int mode) {
-  constexpr int CH = ET<T>::CH;
   const long total = (long)Cinp * 4 * Coutp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+    dst[i] = convt_packed_value<T>(w, i, Cin, Cout, Cinp, Coutp, mode);
+}
+
+template <typename T>
+__device__ __forceinline__ T convt_packed_value(const float* __restrict__ w, long i, int Cin, int Cout, int Cinp, int Coutp,
+                                               int mode) {
+  constexpr int CH = ET<T>::CH;
   const int Np = mode == 0 ? 4 * Coutp : Cinp;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int j = (int)(i % CH);
-    long r = i / CH;
-    const int n = (int)(r % Np);
-    const int kc = (int)(r / Np);
-    int ci, co, q;
-    if (mode == 0) { ci = kc * CH + j; q = n / Coutp; co = n - q * Coutp; }
-    else { const int ncc = Coutp / CH; q = kc / ncc; co = (kc - q * ncc) * CH + j; ci = n; }
-    float v = 0.f;
-    if (ci < Cin && co < Cout) v = w[((long)ci * Cout + co) * 4 + q];
-    dst[i] = from_float<T>(v);
+  const int j = (int)(i % CH);
+  long r = i / CH;
+  const int n = (int)(r % Np);
+  const int kc = (int)(r / Np);
+  int ci, co, q;
+  if (mode == 0) { ci = kc * CH + j; q = n / Coutp; co = n - q * Coutp; }
+  else { const int ncc = Coutp / CH; q = kc / ncc; co = (kc - q * ncc) * CH + j; ci = n; }
+  float v = 0.f;
+  if (ci < Cin && co < Cout) v = w[((long)ci * Cout + co) * 4 + q];
+  return from_float<T>(v);
+}
+
+// Every packed copy a model refreshes after an optimizer step in ONE launch (segk_pack_multi): `table` lists the tensors, a
+// block finds its tensor by its first block index (entries sorted, <= 64 of them) and runs that tensor's routine.
+constexpr int PACK_CONVT_CHUNK = 2048;     // elements of a ConvTranspose weight per block
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const SegkPackEntry* __restrict__ table, int n) {
+  __shared__ float tile[32][32 * 9 + 1];
+  int e = 0;
+  for (int i = 1; i < n; ++i) e = ((int)blockIdx.x >= table[i].block0) ? i : e;     // scalar loop (uniform)
+  const SegkPackEntry t = table[e];
+  const int lid = blockIdx.x - t.block0;
+  if (t.kind == 0) {
+    const int gx = (t.CAp + t.CBp) / 32;
+    pack_conv3x3_both_block<T>(t.w, (T*)t.dst_fwd, (T*)t.dst_dgrad, t.Cout, t.CA, t.CB, t.Coutp, t.CAp, t.CBp, lid % gx, lid / gx,
+                               tile);
+  } else if (t.kind == 1) {
+    const long total = (long)t.CAp * 4 * t.Coutp;
+    const long i0 = (long)lid * PACK_CONVT_CHUNK;
+    for (long i = i0 + threadIdx.x; i < i0 + PACK_CONVT_CHUNK && i < total; i += 256) {
+      ((T*)t.dst_fwd)[i] = convt_packed_value<T>(t.w, i, t.CA, t.Cout, t.CAp, t.Coutp, 0);
+      if (t.dst_dgrad) ((T*)t.dst_dgrad)[i] = convt_packed_value<T>(t.w, i, t.CA, t.Cout, t.CAp, t.Coutp, 1);
+    }
+  } else {
+    float* d = (float*)t.dst_fwd;
+    for (int i = threadIdx.x; i < 4 * t.Coutp; i += 256) {
+      const int c = i % t.Coutp;
+      d[i] = c < t.Cout ? t.w[c] : 0.f;
+    }
   }
 }
 
@@ -308,16 +333,17 @@ int segk_pack_conv3x3_both_impl(const float* w, void* dst_fwd, void* dst_dgrad, 
   return 0;
 }
 
-int segk_pack_conv3x3_multi_impl(const void* table, int n, int total_blocks, int dtype, hipStream_t st) {
-  SEGK_REQUIRE(table && n > 0 && n <= 64 && total_blocks > 0, "pack_conv3x3_multi: bad arguments");
-  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "pack_conv3x3_multi: bad dtype %d", dtype);
+int segk_pack_multi_impl(const void* table, int n, int total_blocks, int dtype, hipStream_t st) {
+  SEGK_REQUIRE(table && n > 0 && n <= 64 && total_blocks > 0, "pack_multi: bad arguments");
+  SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "pack_multi: bad dtype %d", dtype);
   if (dtype == SEGK_DT_BF16)
-    hipLaunchKernelGGL(pack_conv3x3_multi_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, (const SegkPackEntry*)table, n);
+    hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, (const SegkPackEntry*)table, n);
   else
-    hipLaunchKernelGGL(pack_conv3x3_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, st, (const SegkPackEntry*)table, n);
-  SEGK_CHECK_LAUNCH("pack_conv3x3_multi");
+    hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, st, (const SegkPackEntry*)table, n);
+  SEGK_CHECK_LAUNCH("pack_multi");
   return 0;
 }
+int segk_pack_convt_chunk_impl() { return PACK_CONVT_CHUNK; }
 
 int segk_pack_convt_weight_impl(const float* w, void* dst, int Cin, int Cout, int Cinp, int Coutp, int mode, int dtype,
                                 hipStream_t st) {

@@ -41,14 +41,18 @@ int segk_conv_writes_act(int cin_p, int n_p, int dtype); // the layer's kernel c
 int segk_conv_bm(int geo, int unit);      // pixels per tile for a layer with N = unit output channels
 int segk_conv_twl(int bm, int W);         // log2 tile width
 
-// one 3x3 weight of segk_pack_conv3x3_multi's device table (64 bytes; the host builds it as 8 int64 words)
+// one tensor of segk_pack_multi's device table (64 bytes; the host builds it as 8 int64 words)
+//   kind 0: Conv2d 3x3 weight OIHW -> forward + data-gradient layouts   (blocks: (CAp+CBp)/32 * Coutp/32)
+//   kind 1: ConvTranspose2d(k=2,s=2) weight IOHW -> GEMM + un-shuffle layouts; CA = Cin, CAp = Cinp  (blocks: ceil(Cinp*4*Coutp / 2048))
+//   kind 2: ConvTranspose2d bias [Cout] -> fp32 [4][Coutp] (one block); dst_dgrad unused
 struct SegkPackEntry {
-  const float* w;       // OIHW fp32 parameter
+  const float* w;       // fp32 parameter
   void* dst_fwd;        // forward layout
   void* dst_dgrad;      // data-gradient layout (or null)
   int Cout, CA, CB, Coutp, CAp, CBp;
   int block0;           // first block of this tensor in the launch (entries sorted by it)
-  int pad_[3];
+  int kind;
+  int pad_[2];
 };
 static_assert(sizeof(SegkPackEntry) == 64, "SegkPackEntry is 64 bytes");
 

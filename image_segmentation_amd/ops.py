@@ -154,11 +154,12 @@ class PackCache:
 
     def __init__(self):
         self._c = {}
-        self.pairs = {}      # key_a -> (key_b, param, CA, CB, dtype): what repack_stale() refreshes in one launch
+        self.multi = {}      # key_a -> (kind, key_b, param, d0, d1, dtype): what repack_stale() refreshes in one launch
 
     def get_pair(self, key_a, key_b, param, builder, meta=None):
         """Two packed copies made by one builder call (returns the first; the second is served by get(key_b)).
-        meta=(CA, CB, dtype) registers the pair of a 3x3 weight for repack_stale()."""
+        meta=(kind, d0, d1, dtype) registers the pair for repack_stale() (kind 0: 3x3 weight, d = CA, CB; kind 1:
+        ConvTranspose weight)."""
         ver = (param._version, param.data_ptr(), param.device, _OPT_EPOCH[0] if param.requires_grad else -1)
         hit = self._c.get(key_a)
         if hit is None or hit[0] != ver:
@@ -167,8 +168,13 @@ class PackCache:
             self._c[key_a] = hit
             self._c[key_b] = (ver, b)
             if meta is not None:
-                self.pairs[key_a] = (key_b, param) + tuple(meta)
+                self.multi[key_a] = (meta[0], key_b, param) + tuple(meta[1:])
         return hit[1]
+
+    def get_registered(self, key, param, builder, meta):
+        """get() that also registers the single copy for repack_stale() (kind 2: ConvTranspose bias operand)."""
+        self.multi[key] = (meta[0], None, param) + tuple(meta[1:])
+        return self.get(key, param, builder)
 
     def get(self, key, param, builder):
         ver = (param._version, param.data_ptr(), param.device, _OPT_EPOCH[0] if param.requires_grad else -1)
@@ -205,11 +211,32 @@ def pack_conv_both(w, CA, CB, dtype):
     return both[:n], both[n:]
 
 
+_PACK_CONVT_CHUNK = [0]
+
+
+def _entry_geometry(kind, param, d0, d1):
+    """(elements of each destination, words 3..6 of the table entry without block0, blocks) of one registered tensor."""
+    if kind == 0:            # Conv2d 3x3 [Cout][CA+CB][3][3]: d0, d1 = CA, CB
+        Cout = param.shape[0]
+        Coutp, CAp, CBp = pad32(Cout), pad32(d0), (pad32(d1) if d1 else 0)
+        return (CAp + CBp) * 9 * Coutp, (Cout, d0, d1, Coutp, CAp, CBp), (CAp + CBp) // 32 * (Coutp // 32)
+    if kind == 1:            # ConvTranspose2d [Cin][Cout][2][2]
+        Cin, Cout = param.shape[0], param.shape[1]
+        Cinp, Coutp = pad32(Cin), pad32(Cout)
+        if not _PACK_CONVT_CHUNK[0]:
+            _PACK_CONVT_CHUNK[0] = _lib.query("segk_pack_convt_chunk")
+        n = Cinp * 4 * Coutp
+        return n, (Cout, Cin, 0, Coutp, Cinp, 0), (n + _PACK_CONVT_CHUNK[0] - 1) // _PACK_CONVT_CHUNK[0]
+    Cout = param.shape[0]    # kind 2: ConvTranspose2d bias -> fp32 [4][Coutp]
+    return 4 * pad32(Cout), (Cout, 0, 0, pad32(Cout), 0, 0), 1
+
+
 def repack_stale(model):
-    """Refresh every stale (forward, data-gradient) pair of 3x3 weights under `model` with ONE launch
-    (segk_pack_conv3x3_multi) instead of one per weight: called at the top of a model's forward, it does nothing until
-    an optimizer step (or invalidate_packed_weights) moved the epoch.  The pairs are those DoubleConvFn registered on its
-    first training forward; their destination buffers are re-used (every consumer is ordered on the launch stream)."""
+    """Refresh every stale packed copy registered under `model` with ONE launch (segk_pack_multi) instead of one per tensor:
+    the (forward, data-gradient) pairs of the 3x3 and ConvTranspose weights and the ConvTranspose bias operands.  Called at
+    the top of a model's forward, it does nothing until an optimizer step (or invalidate_packed_weights) moved the epoch.
+    The tensors are those the autograd nodes registered on their first training forward (PackCache.multi); their
+    destination buffers are re-used (every consumer is ordered on the launch stream)."""
     st = model.__dict__.get("_segk_pack_state")
     if st is None:
         st = model.__dict__["_segk_pack_state"] = {"epoch": _OPT_EPOCH[0], "caches": None, "tables": {}}
@@ -221,43 +248,51 @@ def repack_stale(model):
         st["caches"] = [m.cache for m in model.modules() if isinstance(getattr(m, "cache", None), PackCache)]
     groups = {}
     for cache in st["caches"]:
-        for key_a, (key_b, param, CA, CB, dtype) in cache.pairs.items():
-            ha, hb = cache._c.get(key_a), cache._c.get(key_b)
-            if ha is None or hb is None or not param.is_cuda or param.dtype != torch.float32 or not param.is_contiguous():
+        for key_a, (kind, key_b, param, d0, d1, dtype) in cache.multi.items():
+            ha = cache._c.get(key_a)
+            hb = cache._c.get(key_b) if key_b is not None else None
+            if ha is None or (key_b is not None and hb is None):
+                continue
+            if not param.is_cuda or param.dtype != torch.float32 or not param.is_contiguous():
                 continue
             ver = (param._version, param.data_ptr(), param.device, _OPT_EPOCH[0] if param.requires_grad else -1)
-            if ha[0] == ver and hb[0] == ver:
+            if ha[0] == ver and (hb is None or hb[0] == ver):
                 continue
-            Cout = param.shape[0]
-            n = (pad32(CA) + (pad32(CB) if CB else 0)) * 9 * pad32(Cout)
-            if ha[1].numel() != n or hb[1].numel() != n or ha[1].dtype != dtype or hb[1].dtype != dtype:
+            n, _, _ = _entry_geometry(kind, param, d0, d1)
+            want = torch.float32 if kind == 2 else dtype
+            if ha[1].numel() != n or ha[1].dtype != want or not ha[1].is_contiguous():
                 continue
-            groups.setdefault((dtype, param.device), []).append((cache, key_a, key_b, ver, param, ha[1], hb[1], CA, CB))
+            if hb is not None and (hb[1].numel() != n or hb[1].dtype != want or not hb[1].is_contiguous()):
+                continue
+            groups.setdefault((dtype, param.device), []).append(
+                (cache, key_a, key_b, ver, param, ha[1], None if hb is None else hb[1], kind, d0, d1))
     for (dtype, dev), items in groups.items():
         if len(items) < 2:
-            continue                 # a single weight goes through the per-weight path
+            continue                 # a single tensor goes through its own path
         for c0 in range(0, len(items), 64):
             chunk = items[c0:c0 + 64]
-            sig = tuple((it[4].data_ptr(), it[5].data_ptr(), it[6].data_ptr(), it[7], it[8]) for it in chunk)
+            sig = tuple((it[4].data_ptr(), it[5].data_ptr(), 0 if it[6] is None else it[6].data_ptr(), it[7], it[8], it[9])
+                        for it in chunk)
             tab = st["tables"].get((dtype, dev, c0))
             if tab is None or tab[0] != sig:
                 import numpy as np
                 words = np.zeros((len(chunk), 8), dtype=np.int64)
                 ints = words.view(np.int32).reshape(len(chunk), 16)
                 blk = 0
-                for i, (_, _, _, _, param, a, b, CA, CB) in enumerate(chunk):
-                    Cout = param.shape[0]
-                    Coutp, CAp, CBp = pad32(Cout), pad32(CA), (pad32(CB) if CB else 0)
-                    words[i, 0], words[i, 1], words[i, 2] = param.data_ptr(), a.data_ptr(), b.data_ptr()
-                    ints[i, 6:13] = (Cout, CA, CB, Coutp, CAp, CBp, blk)
-                    blk += (CAp + CBp) // 32 * (Coutp // 32)
+                for i, (_, _, _, _, param, a, b, kind, d0, d1) in enumerate(chunk):
+                    _, dims, nblk = _entry_geometry(kind, param, d0, d1)
+                    words[i, 0], words[i, 1], words[i, 2] = param.data_ptr(), a.data_ptr(), 0 if b is None else b.data_ptr()
+                    ints[i, 6:12] = dims
+                    ints[i, 12], ints[i, 13] = blk, kind
+                    blk += nblk
                 tab = (sig, torch.from_numpy(words).to(dev), blk)
                 st["tables"][(dtype, dev, c0)] = tab
             with torch.cuda.device(dev):
-                _lib.call("segk_pack_conv3x3_multi", tab[1].data_ptr(), len(chunk), tab[2], _DT[dtype], _stream())
-            for cache, key_a, key_b, ver, _, a, b, _, _ in chunk:
+                _lib.call("segk_pack_multi", tab[1].data_ptr(), len(chunk), tab[2], _DT[dtype], _stream())
+            for cache, key_a, key_b, ver, _, a, b, _, _, _ in chunk:
                 cache._c[key_a] = (ver, a)
-                cache._c[key_b] = (ver, b)
+                if key_b is not None:
+                    cache._c[key_b] = (ver, b)
 
 
 def pack_convt(w, dtype, mode):
@@ -521,16 +556,20 @@ def _bn_momentum(bn):
     return bn.momentum
 
 
-def _convt_fwd(mod, x_t, px, w, b, B, H, W, Cin, Cout, dtype, dev):
+def _convt_fwd(mod, x_t, px, w, b, B, H, W, Cin, Cout, dtype, dev, both=False):
     """ConvTranspose2d(k=2, s=2) forward as one GEMM with a pixel-shuffle store -> NHWC buffer [B,2H,2W,Coutp]."""
     Cinp, Coutp = pad32(Cin), pad32(Cout)
-    wp = mod.cache.get(("tf", dtype), w, lambda: pack_convt(w, dtype, 0))
+    if both:      # a backward will follow: both layouts, registered for the one-launch repack
+        wp = mod.cache.get_pair(("tf", dtype), ("td", dtype), w, lambda: (pack_convt(w, dtype, 0), pack_convt(w, dtype, 1)),
+                                meta=(1, 0, 0, dtype))
+    else:
+        wp = mod.cache.get(("tf", dtype), w, lambda: pack_convt(w, dtype, 0))
 
     def bias4():
         t = torch.zeros((4, Coutp), dtype=torch.float32, device=dev)
         t[:, :Cout] = _param_f32(b)
         return t
-    b4 = None if b is None else mod.cache.get(("tb", dtype), b, bias4)
+    b4 = None if b is None else mod.cache.get_registered(("tb", dtype), b, bias4, meta=(2, 0, 0, dtype))
     out = torch.empty((B, 2 * H, 2 * W, Coutp), dtype=dtype, device=dev)
     with _span("convt_fwd", 2.0 * B * H * W * Cin * 4 * Cout, B * H * W * (Cin + 4 * Cout) * _es(dtype)):
         _lib.call("segk_convt2x2_fwd", px, wp.data_ptr(), _p(b4), out.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype],
@@ -663,7 +702,8 @@ class DoubleConvFn(torch.autograd.Function):
                 raise RuntimeError(f"Sizes of tensors must match except in dimension 1: {tuple(xa.shape)} vs "
                                    f"{(Bu, Cout_u, 2 * Hu, 2 * Wu)} (H and W must be multiples of 16)")
             up_t, pux, _ = _raw(up_x, dtype)
-            ubuf = _convt_fwd(cfg.up_mod, up_t, pux, up_w, up_b, Bu, Hu, Wu, Cin_u, Cout_u, dtype, dev)
+            ubuf = _convt_fwd(cfg.up_mod, up_t, pux, up_w, up_b, Bu, Hu, Wu, Cin_u, Cout_u, dtype, dev,
+                              both=any(ctx.needs_input_grad))
             xb = act_view(ubuf, Cout_u)
             up_dims = (Bu, Hu, Wu, Cin_u, Cout_u)
         CB = 0 if xb is None else xb.shape[1]
@@ -676,9 +716,9 @@ class DoubleConvFn(torch.autograd.Function):
         want_grad = any(ctx.needs_input_grad)
         if training and want_grad:     # a backward will follow: both layouts in one pass per weight
             w1p = mod.cache.get_pair(("w1f", dtype), ("w1d", dtype), w1, lambda: pack_conv_both(w1, CA, CB, dtype),
-                                     meta=(CA, CB, dtype))
+                                     meta=(0, CA, CB, dtype))
             w2p = mod.cache.get_pair(("w2f", dtype), ("w2d", dtype), w2, lambda: pack_conv_both(w2, Cout, 0, dtype),
-                                     meta=(Cout, 0, dtype))
+                                     meta=(0, Cout, 0, dtype))
         else:
             w1p = mod.cache.get(("w1f", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 0))
             w2p = mod.cache.get(("w2f", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 0))
@@ -908,7 +948,7 @@ class ConvT2x2Fn(torch.autograd.Function):
         B, Cin, H, W = x.shape
         Cout = w.shape[1]
         x_t, px, _ = _raw(x, dtype)
-        out = _convt_fwd(mod, x_t, px, w, b, B, H, W, Cin, Cout, dtype, x.device)
+        out = _convt_fwd(mod, x_t, px, w, b, B, H, W, Cin, Cout, dtype, x.device, both=any(ctx.needs_input_grad))
         ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, Cin, Cout)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x_t, w)

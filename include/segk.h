@@ -52,11 +52,16 @@ int segk_pack_conv_weight(const float* w, void* dst, int Cout, int CA, int CB, i
  * fp32 parameter (training re-packs after every optimizer step); dst_dgrad may be NULL */
 int segk_pack_conv3x3_both(const float* w, void* dst_fwd, void* dst_dgrad, int Cout, int CA, int CB, int Coutp, int CAp,
                            int CBp, int dtype, segk_stream_t s);
-/* segk_pack_conv3x3_both for up to 64 weights in ONE launch (every 3x3 weight of a model after an optimizer step).
+/* Up to 64 packed copies refreshed by ONE launch (everything a model re-packs after an optimizer step).
  * table: device array of n 64-byte entries { const float* w; void* dst_fwd; void* dst_dgrad; int32 Cout, CA, CB, Coutp,
- * CAp, CBp; int32 block0; int32 pad[3] } sorted by block0 = first block of the tensor, a tensor taking
- * (CAp+CBp)/32 * Coutp/32 blocks; total_blocks = their sum.  The table must stay valid until the launch has run. */
-int segk_pack_conv3x3_multi(const void* table, int n, int total_blocks, int dtype, segk_stream_t s);
+ * CAp, CBp; int32 block0; int32 kind; int32 pad[2] } sorted by block0 = first block of the tensor; total_blocks = the sum
+ * of the entries' block counts.  The table must stay valid until the launch has run.
+ *   kind 0: segk_pack_conv3x3_both (blocks (CAp+CBp)/32 * Coutp/32);
+ *   kind 1: segk_pack_convt_weight, mode 0 into dst_fwd and mode 1 into dst_dgrad (may be NULL), CA = Cin, CAp = Cinp
+ *           (blocks ceil(Cinp*4*Coutp / segk_pack_convt_chunk()));
+ *   kind 2: ConvTranspose2d bias w [Cout] -> dst_fwd fp32 [4][Coutp], the bias4 operand of segk_convt2x2_fwd (1 block). */
+int segk_pack_multi(const void* table, int n, int total_blocks, int dtype, segk_stream_t s);
+int segk_pack_convt_chunk(void);
 /* ConvTranspose2d(k=2,s=2) weight IOHW fp32 [Cin][Cout][2][2] -> MFMA layout; mode 0 forward, 1 data-gradient */
 int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cinp, int Coutp, int mode, int dtype,
                            segk_stream_t s);
