@@ -254,12 +254,20 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int m = ry; m < NB; m += 32) {
-      const float2 v = ((const float2*)part)[(size_t)m * C + c];
-      s1 += (double)v.x;
-      s2 += (double)v.y;
+  if (c < C) {
+    // four independent rows in flight per pass (latency-bound walk); fixed order of additions: bit-stable
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int m = ry; m < NB; m += 128) {
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = (m + 32 * u < NB) ? ((const float2*)part)[(size_t)(m + 32 * u) * C + c] : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a1[u] += (double)v[u].x; a2[u] += (double)v[u].y; }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s1 += a1[u]; s2 += a2[u]; }
+  }
   sh[ry][cx][0] = s1;
   sh[ry][cx][1] = s2;
   __syncthreads();

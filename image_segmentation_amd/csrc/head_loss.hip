@@ -339,8 +339,20 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
   static_assert(LP <= 32, "one column lane per partial");
   const int t = threadIdx.x, cx = t & 31, ry = t >> 5;
   double acc = 0.0;
-  if (cx < LP)
-    for (int b = ry; b < NB; b += 8) acc += (double)part[(size_t)b * LP + cx];
+  if (cx < LP) {
+    // eight independent partial rows in flight per pass (the walk is latency-bound otherwise); the order of the additions
+    // stays fixed: bit-stable
+    double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int b = ry; b < NB; b += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (b + 8 * u < NB) ? part[(size_t)(b + 8 * u) * LP + cx] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += (double)v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += a8[u];
+  }
   sh[ry][cx] = acc;
   __syncthreads();
   if (t < LP) {
