@@ -151,6 +151,56 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                     mean_out, rstd_out, sh);
 }
 
+// training mode, few partial rows (MT <= 1024: every layer but the 128-channel ones at 128x128 and above): one block of
+// 32 row lanes x 32 channels walks all rows itself, eight rows in flight per lane, and finishes -- no second stage at all
+__global__ __launch_bounds__(1024) void bn_stats_finalize_small_kernel(const float* __restrict__ part, int MT, int C,
+                                                                       int C_real, double count, const float* conv_bias,
+                                                                       const float* gamma, const float* beta, float* rmean,
+                                                                       float* rvar, float momentum, float eps, float* scale,
+                                                                       float* shift, float* mean_out, float* rstd_out) {
+  __shared__ double sh[32][32][2];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double a1[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, a2[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int m = ry; m < MT; m += 256) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = (m + 32 * u < MT) ? ((const float2*)part)[(size_t)(m + 32 * u) * C + c] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a1[u] += (double)v[u].x; a2[u] += (double)v[u].y; }
+  }
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { s1 += a1[u]; s2 += a2[u]; }     // fixed order: bit-stable
+  sh[ry][cx][0] = s1;
+  sh[ry][cx][1] = s2;
+  __syncthreads();
+  if (ry != 0) return;
+  s1 = 0.0; s2 = 0.0;
+  for (int r = 0; r < 32; ++r) { s1 += sh[r][cx][0]; s2 += sh[r][cx][1]; }
+  if (c >= C_real) {  // padded channel: stays identically zero
+    scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; rstd_out[c] = 0.f;
+    return;
+  }
+  const float g = gamma[c], be = beta[c];
+  const float cb = conv_bias ? conv_bias[c] : 0.f;
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = g * rstd;
+  scale[c] = sc;
+  shift[c] = be - (float)mean * sc;      // applied to the bias-free conv output: the bias cancels
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  if (rmean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * ((float)mean + cb);
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
 // training mode, ONE launch: grid (C/32, NCH) blocks reduce their chunk of the per-tile partials (stage A); the block that
 // arrives last for a channel group finishes it (stage B over the NCH chunk sums, in chunk order: bit-stable)
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int MT, int C, int C_real,
@@ -533,6 +583,12 @@ int segk_bn_finalize_impl(const float* part, int MT, int C, int C_real, double c
   else SEGK_REQUIRE(rmean && rvar, "bn_finalize: eval needs running statistics");
   // the stats buffer carries NCH*C*2 doubles of scratch behind the [MT][C][2] float partials
   double* scratch = part ? (double*)(const_cast<float*>(part) + (size_t)MT * C * 2) : nullptr;
+  if (training && MT <= 1024) {
+    hipLaunchKernelGGL(bn_stats_finalize_small_kernel, dim3(C / 32), dim3(1024), 0, st, part, MT, C, C_real, count, conv_bias,
+                       gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean, rstd);
+    SEGK_CHECK_LAUNCH("bn_stats_finalize_small");
+    return 0;
+  }
   if (training) {
     SEGK_REQUIRE(C / 32 <= TICKET_GROUPS, "bn_finalize: at most %d channels", 32 * TICKET_GROUPS);
     static unsigned* ticket_base[SEGK_MAX_DEVICES] = {};      // per device: the symbol lives in that device's module image

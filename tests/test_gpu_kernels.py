@@ -267,6 +267,46 @@ def test_wgrad_prologue(ops, dtype):
     assert (dw - w.grad).abs().max().item() < tol(dtype, 1) * np.sqrt(B * H * W) * 0.5
 
 
+@pytest.mark.parametrize("case", [(7, 64), (512, 96), (1024, 32), (1025, 64), (4096, 64), (3000, 1024)])
+def test_bn_finalize_from_partial_rows(ops, case):
+    """segk_bn_finalize in training mode, both launch forms (one block per channel group up to 1024 partial rows; chunked
+    blocks whose last arriver finishes the group above that): scale / shift / mean / rstd and the running statistics from
+    per-tile (sum, sum of squares) rows, against float64 arithmetic on the same rows (reference semantics:
+    torch.nn.BatchNorm2d at unet/unet.py:17,20 -- biased variance to normalise, unbiased into running_var)."""
+    import types
+    MT, C = case
+    Cr = C - 5 if C > 32 else C
+    g = torch.Generator().manual_seed(MT * 131 + C)
+    rows = torch.rand((MT, C, 2), generator=g, dtype=torch.float32)
+    rows[:, :, 0] = rows[:, :, 0] * 2 - 1                       # sums of either sign
+    rows[:, :, 1] = rows[:, :, 1] * 4 + 3.0                     # sums of squares: keeps the variance positive
+    count = float(MT * 4)
+    gamma, beta, cb = fill((Cr,), 1, 0.5, 1.5), fill((Cr,), 2, -0.5, 0.5), fill((Cr,), 3, -0.2, 0.2)
+    rm0, rv0 = fill((Cr,), 4, -0.1, 0.1), fill((Cr,), 5, 0.5, 1.5)
+    bn = types.SimpleNamespace(running_mean=dev(rm0.clone()), running_var=dev(rv0.clone()))
+    from image_segmentation_amd import _lib
+    st = torch.empty((_lib.query("segk_bn_stats_floats", MT, C),), dtype=torch.float32, device="cuda")
+    st[:MT * C * 2] = dev(rows).reshape(-1)
+    for rep in range(3):                                        # repeated launches re-use the ticket counters
+        bn.running_mean.copy_(dev(rm0)); bn.running_var.copy_(dev(rv0))
+        sc, sh, mu, rs = ops.bn_finalize(st, MT, Cr, count, dev(cb), dev(gamma), dev(beta), bn.running_mean, bn.running_var,
+                                         0.1, 1e-5, True, "cuda")
+        torch.cuda.synchronize()
+        s = rows.double().sum(0)[:Cr]
+        mean = s[:, 0] / count
+        var = (s[:, 1] / count - mean * mean).clamp(min=0)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        assert (back(mu)[:Cr].double() - mean).abs().max() < 1e-6
+        assert ((back(rs)[:Cr].double() - rstd).abs() / rstd).max() < 1e-6
+        assert (back(sc)[:Cr].double() - gamma.double() * rstd).abs().max() < 1e-5
+        assert (back(sh)[:Cr].double() - (beta.double() - mean * gamma.double() * rstd)).abs().max() < 1e-5
+        assert back(sc)[Cr:].abs().max().item() == 0 if C > Cr else True
+        want_rm = 0.9 * rm0.double() + 0.1 * (mean + cb.double())
+        want_rv = 0.9 * rv0.double() + 0.1 * var * count / (count - 1)
+        assert (back(bn.running_mean).double() - want_rm).abs().max() < 1e-6
+        assert (back(bn.running_var).double() - want_rv).abs().max() < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_bn_relu_bwd(ops, dtype):
     B, C, H, W = 3, 40, 10, 14
