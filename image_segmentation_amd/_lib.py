@@ -47,7 +47,7 @@ SIGNATURES = {
     "segk_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "segk_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_maxpool_bwd_stat_blocks": (_i, [_i, _i, _i, _i, _i]),
-    "segk_maxpool2x2_bwd_bnstat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _vp]),
+    "segk_maxpool2x2_bwd_bnstat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _vp, _i, _vp]),
     "segk_bn_relu_bwd_from_part": (_i, [_vp, _vp, _vp, _fp, _fp, _fp, _fp, _l, _i, _i, _fp, _i, _fp, _fp, _fp, _i, _vp]),
     "segk_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_bilinear_bwd": (_i, [_vp, _vp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -16,7 +16,7 @@ int segk_channel_sum_impl(const void*, long, int, int, float*, float*, int, hipS
 int segk_maxpool_fwd_impl(const void*, void*, int, int, int, int, int, hipStream_t);
 int segk_maxpool_bwd_impl(const void*, const void*, void*, int, int, int, int, int, int, hipStream_t);
 int segk_maxpool_bwd_bnstat_impl(const void*, const void*, void*, int, int, int, int, int, const float*, const float*,
-                                 const float*, const float*, float*, int, hipStream_t);
+                                 const float*, const float*, float*, const void*, int, hipStream_t);
 int segk_bn_bwd_from_part_impl(const void*, const void*, void*, const float*, const float*, const float*, const float*, long,
                                int, int, const float*, int, float*, float*, float*, int, hipStream_t);
 int segk_nchw_to_nhwc_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
@@ -239,9 +239,10 @@ int segk_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int H, i
 }
 int segk_maxpool2x2_bwd_bnstat(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate,
                                const float* scale, const float* shift, const float* mean, const float* rstd, float* part,
-                               int dtype, segk_stream_t s) {
+                               const void* z, int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "maxpool2x2_bwd_bnstat: bad dtype %d", dtype);
-  return segk_maxpool_bwd_bnstat_impl(x, dy, dx, B, H, W, Cp, accumulate, scale, shift, mean, rstd, part, dtype, (hipStream_t)s);
+  return segk_maxpool_bwd_bnstat_impl(x, dy, dx, B, H, W, Cp, accumulate, scale, shift, mean, rstd, part, z, dtype,
+                                      (hipStream_t)s);
 }
 int segk_bn_relu_bwd_from_part(const void* dy, const void* z, void* dz, const float* scale, const float* shift,
                                const float* mean, const float* rstd, long P, int Cp, int C, const float* part, int nb,

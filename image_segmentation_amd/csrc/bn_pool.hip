@@ -429,27 +429,42 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 // pool gradient): the kernel also accumulates that BatchNorm's backward reductions sum(g), sum(g * xhat) with
 // g = dx where y > 0 -- xhat is recovered from y itself where the ReLU is active, xhat = (y - shift) * rstd / scale - mean * rstd,
 // and pixels with y == 0 contribute nothing -- so the block's bn_bwd_reduce pass (a read of dx and z) disappears.
-// Needs a power-of-two number of channel vectors (a thread then keeps its channels) and scale != 0.
+// Needs a power-of-two number of channel vectors (a thread then keeps its channels); channels with scale == 0 or
+// |scale| < |shift| / 16 take xhat from z instead (see from_z below; without z they would get xhat = -mean * rstd).
 template <typename T, bool STAT>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           T* __restrict__ dx, int B, int H, int W, int C,
                                                           int accumulate, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ mean,
-                                                          const float* __restrict__ rstd, float* __restrict__ part) {
+                                                          const float* __restrict__ rstd, float* __restrict__ part,
+                                                          const T* __restrict__ z) {
   using E = ET<T>;
   const int Ho = H >> 1, Wo = W >> 1, CV = C / E::VEC;
   const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;  // also visit the odd border (gradient zero there)
   const long total = (long)B * Hc * Wc * CV;
   float xa[E::VEC], xb[E::VEC], sg[E::VEC], sgx[E::VEC];
+  // xhat cannot be recovered from y where scale == 0 (y = relu(shift) is constant), and only badly where |scale| << |shift|
+  // (the rounding of y is amplified by 1 / scale).  A thread whose channels include such a one reads z (when the caller
+  // passed it) and takes xhat = (z - mean) * rstd like the stand-alone reduction; every other thread never touches z.
+  bool from_z = false;
   if (STAT) {
     const int cv0 = threadIdx.x % CV;              // fixed for the thread: 256 and the grid stride are multiples of CV
 #pragma unroll
     for (int j = 0; j < E::VEC; ++j) {
       const int c = cv0 * E::VEC + j;
-      const float sc = scale[c], rs = rstd[c];
+      const float sc = scale[c], rs = rstd[c], sh = shift[c];
+      from_z = from_z || (z != nullptr && (sc == 0.f || fabsf(sc) * 16.f < fabsf(sh)));
       xa[j] = sc != 0.f ? rs / sc : 0.f;
-      xb[j] = -shift[c] * xa[j] - mean[c] * rs;
+      xb[j] = -sh * xa[j] - mean[c] * rs;
       sg[j] = 0.f; sgx[j] = 0.f;
+    }
+    if (from_z) {                                  // xhat = z * rstd - mean * rstd
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) {
+        const int c = cv0 * E::VEC + j;
+        xa[j] = rstd[c];
+        xb[j] = -mean[c] * rstd[c];
+      }
     }
   }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -484,8 +499,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
       const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
       if (yy >= H || xx >= W) continue;
       T* dst = dx + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC;
-      float o[E::VEC];
+      float o[E::VEC], zf[E::VEC];
       if (accumulate) unpack16<T>(*(const uint4*)dst, o);
+      if (STAT && from_z) unpack16<T>(*(const uint4*)(z + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC), zf);
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) {
         const float r = (inwin && sel[j] == k) ? g[j] : 0.f;
@@ -493,7 +509,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         if (STAT) {
           const float gg = v[k][j] > 0.f ? o[j] : 0.f;
           sg[j] += gg;
-          sgx[j] = fmaf(gg, fmaf(v[k][j], xa[j], xb[j]), sgx[j]);
+          sgx[j] = fmaf(gg, fmaf(from_z ? zf[j] : v[k][j], xa[j], xb[j]), sgx[j]);
         }
       }
       *(uint4*)dst = pack16<T>(o);
@@ -743,10 +759,10 @@ int segk_maxpool_bwd_impl(const void* x, const void* dy, void* dx, int B, int H,
   if (g > 8192) g = 8192;
   if (dtype == SEGK_DT_BF16)
     hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, false>), dim3((int)g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
-                       (bf16_t*)dx, B, H, W, C, accumulate, nullptr, nullptr, nullptr, nullptr, nullptr);
+                       (bf16_t*)dx, B, H, W, C, accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   else
     hipLaunchKernelGGL((maxpool_bwd_kernel<float, false>), dim3((int)g), dim3(256), 0, st, (const float*)x, (const float*)dy,
-                       (float*)dx, B, H, W, C, accumulate, nullptr, nullptr, nullptr, nullptr, nullptr);
+                       (float*)dx, B, H, W, C, accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   SEGK_CHECK_LAUNCH("maxpool_bwd");
   return 0;
 }
@@ -764,16 +780,16 @@ int segk_maxpool_bwd_stat_blocks(int B, int H, int W, int C, int dtype) {
 
 int segk_maxpool_bwd_bnstat_impl(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int accumulate,
                                  const float* scale, const float* shift, const float* mean, const float* rstd, float* part,
-                                 int dtype, hipStream_t st) {
+                                 const void* z, int dtype, hipStream_t st) {
   SEGK_REQUIRE(x && dy && dx && scale && shift && mean && rstd && part, "maxpool_bwd_bnstat: null pointer");
   const int g = segk_maxpool_bwd_stat_blocks(B, H, W, C, dtype);
   SEGK_REQUIRE(g > 0, "maxpool_bwd_bnstat: shape not served (channel vectors must be a power of two)");
   if (dtype == SEGK_DT_BF16)
     hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, true>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
-                       (bf16_t*)dx, B, H, W, C, accumulate, scale, shift, mean, rstd, part);
+                       (bf16_t*)dx, B, H, W, C, accumulate, scale, shift, mean, rstd, part, (const bf16_t*)z);
   else
     hipLaunchKernelGGL((maxpool_bwd_kernel<float, true>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)dy,
-                       (float*)dx, B, H, W, C, accumulate, scale, shift, mean, rstd, part);
+                       (float*)dx, B, H, W, C, accumulate, scale, shift, mean, rstd, part, (const float*)z);
   SEGK_CHECK_LAUNCH("maxpool_bwd_bnstat");
   return 0;
 }

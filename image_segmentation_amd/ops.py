@@ -834,7 +834,7 @@ class DoubleConvFn(torch.autograd.Function):
                         part = _f32(nb * Coutp * 2, dev)
                         _lib.call("segk_maxpool2x2_bwd_bnstat", y.data_ptr(), pdp, pdy, B, H, W, Coutp, acc,
                                   sc2.data_ptr(), sh2.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), part.data_ptr(),
-                                  _DT[dtype], _stream())
+                                  z2.data_ptr(), _DT[dtype], _stream())
                         ready = (part, nb)
                     else:
                         _lib.call("segk_maxpool2x2_bwd", y.data_ptr(), pdp, pdy, B, H, W, Coutp, acc, _DT[dtype],

@@ -52,7 +52,14 @@ class ClipVisionPlan:
             w = torch.cat([attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight], 0).detach().float()
             b = torch.cat([attn.q_proj.bias, attn.k_proj.bias, attn.v_proj.bias], 0).detach().float().contiguous()
             return ops.pack_conv(w.reshape(w.shape[0], -1, 1, 1).contiguous(), w.shape[1], 0, dtype, 0, taps=1), b
-        return self.cache.get((key, dtype), attn.q_proj.weight, build)
+        # the fused copy depends on six tensors: the cache entry follows q_proj.weight, the other five are part of the key
+        others = (attn.k_proj.weight, attn.v_proj.weight, attn.q_proj.bias, attn.k_proj.bias, attn.v_proj.bias)
+        sig = tuple((t._version, t.data_ptr()) for t in others)
+        full = (key, dtype, sig)
+        if full not in self.cache._c:     # drop the copy made for an older state of the five (at most one per layer lives)
+            for k in [k for k in self.cache._c if k[:2] == (key, dtype)]:
+                del self.cache._c[k]
+        return self.cache.get(full, attn.q_proj.weight, build)
 
 
 def _f32(p):

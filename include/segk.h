@@ -153,7 +153,11 @@ int segk_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int H, i
 int segk_maxpool_bwd_stat_blocks(int B, int H, int W, int Cp, int dtype);
 int segk_maxpool2x2_bwd_bnstat(const void* x, const void* dy, void* dx, int B, int H, int W, int Cp, int accumulate,
                                const float* scale, const float* shift, const float* mean, const float* rstd, float* part,
-                               int dtype, segk_stream_t s);
+                               const void* z, int dtype, segk_stream_t s);
+/* z (may be NULL): the block's pre-activation [B,H,W,Cp].  xhat is recovered from x = relu(z*scale+shift) itself except
+ * for channels where that is impossible or ill-conditioned (scale == 0, |scale| < |shift|/16): the threads owning such a
+ * channel read z and take xhat = (z - mean) * rstd, exactly like segk_bn_relu_bwd's own reduction; with z == NULL those
+ * channels get xhat = -mean * rstd (wrong dgamma for them). */
 int segk_bn_relu_bwd_from_part(const void* dy, const void* z, void* dz, const float* scale, const float* shift,
                                const float* mean, const float* rstd, long P, int Cp, int C, const float* part, int nb,
                                float* dgamma, float* dbeta, float* coef, int dtype, segk_stream_t s);

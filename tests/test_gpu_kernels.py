@@ -453,14 +453,21 @@ def test_pack_both_layouts_matches_single_packs(ops, dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 64, 16, 24, 1), (1, 128, 9, 14, 1), (2, 32, 8, 8, 0), (1, 1024, 4, 6, 1)])
-def test_maxpool_bwd_with_bn_reductions(ops, dtype, case):
+@pytest.mark.parametrize("degenerate", [False, True])
+def test_maxpool_bwd_with_bn_reductions(ops, dtype, case, degenerate):
     """segk_maxpool2x2_bwd_bnstat: same dx as the plain pooling backward, and partials whose finalize + apply
-    (segk_bn_relu_bwd_from_part) reproduce the three-kernel BatchNorm backward on that dx."""
+    (segk_bn_relu_bwd_from_part) reproduce the three-kernel BatchNorm backward on that dx.  degenerate: channels with
+    gamma == 0 and with |gamma| = 1e-3 |beta|, where xhat cannot be recovered from the block output: the kernel takes it
+    from z for the threads that own such a channel."""
     from image_segmentation_amd import _lib
     B, C, H, W, acc = case
     s = torch.cuda.current_stream().cuda_stream
     z = fill((B, H, W, C), 1, -2, 2)
     gamma, beta = fill((C,), 2, 0.5, 1.5), fill((C,), 3, -0.5, 0.5)
+    if degenerate:
+        gamma[1] = 0.0; beta[1] = 0.4                    # y = relu(beta) everywhere
+        gamma[C - 3] = 0.0; beta[C - 3] = -0.2            # y = 0 everywhere
+        gamma[10] = 1e-3 * beta[10].abs().clamp(min=0.1); beta[10] = beta[10].abs().clamp(min=0.1)
     mu, var = z.reshape(-1, C).mean(0), z.reshape(-1, C).var(0, unbiased=False)
     rs = 1.0 / torch.sqrt(var + 1e-5)
     sc, sh = gamma * rs, beta - mu * gamma * rs
@@ -478,7 +485,7 @@ def test_maxpool_bwd_with_bn_reductions(ops, dtype, case):
     assert nb > 0
     part = torch.empty(nb * C * 2, device="cuda")
     _lib.call("segk_maxpool2x2_bwd_bnstat", yd.data_ptr(), dypd.data_ptr(), dx_new.data_ptr(), B, H, W, C, acc, scd.data_ptr(),
-              shd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), part.data_ptr(), dt, s)
+              shd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), part.data_ptr(), zd.data_ptr(), dt, s)
     assert torch.equal(dx_new, dx_ref)
     P = B * H * W
     dz_a, dz_b = torch.empty_like(dx_ref), torch.empty_like(dx_ref)
