@@ -457,11 +457,27 @@ def bn_finalize(stats, tiles, C, count, conv_bias, bn_w, bn_b, rmean, rvar, mome
     return scale, shift, mean, rstd
 
 
-def bn_relu_bwd(dy_ptr, z_ptr, dz_ptr, scale, shift, mean, rstd, P, C, dtype, dev, ready=None):
+def bn_relu_bwd(dy_ptr, z_ptr, dz_ptr, scale, shift, mean, rstd, P, C, dtype, dev, ready=None, frozen=False):
     """ready = (partials, rows) when the kernel that wrote dy already accumulated the reductions
-    (segk_maxpool2x2_bwd_bnstat): only finalize + apply run."""
+    (segk_maxpool2x2_bwd_bnstat): only finalize + apply run.
+    frozen: the BatchNorm ran on its running statistics (eval mode), i.e. it is a fixed affine map: dz = scale * g with no
+    mean terms, dgamma = sum(g * xhat), dbeta = sum(g).  Served by the same kernels in two calls (the reductions with
+    their apply pass discarded, then an apply pass from all-zero partials) -- not a hot path."""
     Cp = pad32(C)
     dgamma, dbeta = _f32(C, dev), _f32(C, dev)
+    if frozen:
+        nb = _lib.query("segk_bn_bwd_blocks", P, Cp, _DT[dtype])
+        part, coef = _f32(nb * Cp * 2, dev), _f32(2 * Cp, dev)
+        scratch = torch.empty((P * Cp,), dtype=dtype, device=dev)
+        _lib.call("segk_bn_relu_bwd", dy_ptr, z_ptr, scratch.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), P, Cp, C, part.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(),
+                  _DT[dtype], _stream())
+        zero_part = torch.zeros((Cp * 2,), dtype=torch.float32, device=dev)
+        unused_g, unused_b = _f32(C, dev), _f32(C, dev)
+        _lib.call("segk_bn_relu_bwd_from_part", dy_ptr, z_ptr, dz_ptr, scale.data_ptr(), shift.data_ptr(),
+                  mean.data_ptr(), rstd.data_ptr(), P, Cp, C, zero_part.data_ptr(), 1, unused_g.data_ptr(), unused_b.data_ptr(),
+                  coef.data_ptr(), _DT[dtype], _stream())
+        return dgamma, dbeta
     if ready is not None:
         part, nb = ready
         coef = _f32(2 * Cp, dev)
@@ -790,8 +806,7 @@ class DoubleConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        if not ctx.training:
-            raise NotImplementedError("DoubleConvReLU backward requires train() mode (batch-statistics BatchNorm)")
+        frozen = not ctx.training      # eval mode: both BatchNorms are fixed affine maps (running statistics)
         (xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2, a1, y, up_t, up_w, head_w) = ctx.saved_tensors
         cfg, dtype = ctx.cfg, ctx.dtype
         mod = cfg.mod
@@ -844,7 +859,8 @@ class DoubleConvFn(torch.autograd.Function):
 
         # ---- second conv: BN2+ReLU backward, data gradient, weight gradient
         dz2 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
-        dg2, dbe2 = bn_relu_bwd(pdy, z2.data_ptr(), dz2.data_ptr(), sc2, sh2, mu2, rs2, P, Cout, dtype, dev, ready=ready)
+        dg2, dbe2 = bn_relu_bwd(pdy, z2.data_ptr(), dz2.data_ptr(), sc2, sh2, mu2, rs2, P, Cout, dtype, dev, ready=ready,
+                                frozen=frozen)
         del keep
         w2d = mod.cache.get(("w2d", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 1))
         da1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
@@ -858,7 +874,8 @@ class DoubleConvFn(torch.autograd.Function):
         del slabs, dz2
 
         # ---- first conv (dz1 overwrites da1 in place: da1 is private to this function)
-        dg1, dbe1 = bn_relu_bwd(da1.data_ptr(), z1.data_ptr(), da1.data_ptr(), sc1, sh1, mu1, rs1, P, Cout, dtype, dev)
+        dg1, dbe1 = bn_relu_bwd(da1.data_ptr(), z1.data_ptr(), da1.data_ptr(), sc1, sh1, mu1, rs1, P, Cout, dtype, dev,
+                                frozen=frozen)
         dz1 = da1
         dxa = dxb = None
         dxb_buf, chan_sum = None, None
@@ -883,9 +900,14 @@ class DoubleConvFn(torch.autograd.Function):
         slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev, alg=(Cout, CA + CB))
         dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev, param=w1)
         del slabs
-        # conv biases ahead of a batch-statistics BatchNorm have an identically zero gradient
-        db1 = _zero_grad_like(Cout, dev) if ctx.has_bias[0] else None
-        db2 = _zero_grad_like(Cout, dev) if ctx.has_bias[1] else None
+        # conv biases ahead of a batch-statistics BatchNorm have an identically zero gradient; ahead of a frozen one the
+        # bias is part of the affine map: d(bias) = sum(dz) = scale * sum(g)
+        if frozen:
+            db1 = sc1[:Cout] * dbe1 if ctx.has_bias[0] else None
+            db2 = sc2[:Cout] * dbe2 if ctx.has_bias[1] else None
+        else:
+            db1 = _zero_grad_like(Cout, dev) if ctx.has_bias[0] else None
+            db2 = _zero_grad_like(Cout, dev) if ctx.has_bias[1] else None
 
         d_up_x = d_up_w = d_up_b = None
         if has_up:

@@ -425,3 +425,39 @@ def test_head_on_preactivation_matches_head_on_block_output(seg, dtype):
         b = out[False][1][n]
         assert (a - b).norm() <= rel * b.norm() + 1e-6, (n, (a - b).norm().item(), b.norm().item())
     seg.set_compute_dtype(torch.bfloat16)
+
+
+def test_eval_mode_backward_matches_oracle(seg):
+    """Backward through an eval() model (BatchNorm on its running statistics: frozen-BN fine-tuning, input gradients): the
+    stock modules of the reference support it, so do the mirrors -- dz = scale * g, dgamma / dbeta from the running
+    statistics, and a NON-zero conv bias gradient (the bias no longer cancels).  fp32 against the oracle's autograd."""
+    seg.set_compute_dtype(torch.float32)
+    try:
+        ref = unet_ref.unet(3, 3); fill_module(ref, 1000)
+        m = seg.unet(3, 3); fill_module(m, 1000)
+        k = 0
+        for mod in ref.modules():                      # running statistics away from their initial (0, 1)
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(fill(tuple(mod.running_mean.shape), 300 + k, -0.2, 0.2))
+                mod.running_var.copy_(fill(tuple(mod.running_var.shape), 400 + k, 0.5, 1.5))
+                k += 1
+        m.load_state_dict(ref.state_dict())
+        ref.eval(); m.cuda().eval()
+        X = fill((2, 3, 32, 48), 1, 0, 1); Y = labels((2, 32, 48), 2, 3)
+        Xr = X.clone().requires_grad_(True); Xg = X.clone().cuda().requires_grad_(True)
+        lr = ref(Xr); losses_ref.cross_entropy(lr, Y).backward()
+        lg = m(Xg); seg.CrossEntropyLoss()(lg, Y.cuda()).backward()
+        assert np.abs(cpu(lg) - lr.detach().numpy()).max() < 1e-3
+        assert (Xg.grad.cpu() - Xr.grad).norm() <= 2e-3 * Xr.grad.norm() + 1e-9
+        rg = {n: p.grad for n, p in ref.named_parameters()}
+        nonzero_bias = 0
+        for n, p in m.named_parameters():
+            a, b = p.grad.float().cpu(), rg[n]
+            assert (a - b).norm() <= 2e-3 * b.norm() + 1e-7, (n, (a - b).norm().item(), b.norm().item())
+            if n.endswith(".bias") and "doubleConvReLU.0" in n or n.endswith("doubleConvReLU.3.bias"):
+                nonzero_bias += int(b.norm() > 0)
+        assert nonzero_bias > 0
+        for (n, a), (_, b) in zip(m.named_buffers(), ref.named_buffers()):      # eval mode leaves the buffers alone
+            assert torch.equal(a.cpu(), b), n
+    finally:
+        seg.set_compute_dtype(torch.bfloat16)
