@@ -445,7 +445,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   float xa[E::VEC], xb[E::VEC], sg[E::VEC], sgx[E::VEC];
   // xhat cannot be recovered from y where scale == 0 (y = relu(shift) is constant), and only badly where |scale| << |shift|
   // (the rounding of y is amplified by 1 / scale).  A thread whose channels include such a one reads z (when the caller
-  // passed it) and takes xhat = (z - mean) * rstd like the stand-alone reduction; every other thread never touches z.
+  // passed it) and takes xhat = (z - mean) * rstd like the stand-alone reduction, in a second pass of its own after the
+  // main loop; every other thread never touches z.
   bool from_z = false;
   if (STAT) {
     const int cv0 = threadIdx.x % CV;              // fixed for the thread: 256 and the grid stride are multiples of CV
@@ -458,15 +459,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
       xb[j] = -sh * xa[j] - mean[c] * rs;
       sg[j] = 0.f; sgx[j] = 0.f;
     }
-    if (from_z) {                                  // xhat = z * rstd - mean * rstd
-#pragma unroll
-      for (int j = 0; j < E::VEC; ++j) {
-        const int c = cv0 * E::VEC + j;
-        xa[j] = rstd[c];
-        xb[j] = -mean[c] * rstd[c];
-      }
-    }
   }
+#ifdef SEGK_POOL_NO_Z
+  from_z = false;                                  // diagnostic build: the kernel without its rare path (A/B of its cost)
+#endif
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int cv = (int)(i % CV);
     long p = i / CV;
@@ -499,9 +495,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
       const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
       if (yy >= H || xx >= W) continue;
       T* dst = dx + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC;
-      float o[E::VEC], zf[E::VEC];
+      float o[E::VEC];
       if (accumulate) unpack16<T>(*(const uint4*)dst, o);
-      if (STAT && from_z) unpack16<T>(*(const uint4*)(z + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC), zf);
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) {
         const float r = (inwin && sel[j] == k) ? g[j] : 0.f;
@@ -509,7 +504,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         if (STAT) {
           const float gg = v[k][j] > 0.f ? o[j] : 0.f;
           sg[j] += gg;
-          sgx[j] = fmaf(gg, fmaf(from_z ? zf[j] : v[k][j], xa[j], xb[j]), sgx[j]);
+          sgx[j] = fmaf(gg, fmaf(v[k][j], xa[j], xb[j]), sgx[j]);
         }
       }
       *(uint4*)dst = pack16<T>(o);
@@ -517,6 +512,35 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   }
   if (STAT) {
     __shared__ float red[256][2 * E::VEC + 1];
+    if (from_z) {
+      // Rare second pass of this thread over ITS OWN items (a separate loop: the main loop above keeps its registers):
+      // sum(g * xhat) again with xhat = (z - mean) * rstd, from the dx values the thread itself wrote (program order makes
+      // them visible to it), y for the ReLU mask, and z
+#pragma unroll
+      for (int j = 0; j < E::VEC; ++j) sgx[j] = 0.f;
+      for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        long p = i / CV;
+        const int xo = (int)(p % Wc); p /= Wc;
+        const int yo = (int)(p % Hc);
+        const int b = (int)(p / Hc);
+        for (int k = 0; k < 4; ++k) {
+          const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
+          if (yy >= H || xx >= W) continue;
+          const size_t off = (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC;
+          float fy[E::VEC], fd[E::VEC], fz[E::VEC];
+          unpack16<T>(*(const uint4*)(x + off), fy);
+          unpack16<T>(*(const uint4*)(dx + off), fd);
+          unpack16<T>(*(const uint4*)(z + off), fz);
+#pragma unroll
+          for (int j = 0; j < E::VEC; ++j) {
+            const int c = cv * E::VEC + j;
+            const float gg = fy[j] > 0.f ? fd[j] : 0.f;
+            sgx[j] = fmaf(gg, (fz[j] - mean[c]) * rstd[c], sgx[j]);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < E::VEC; ++j) { red[threadIdx.x][j] = sg[j]; red[threadIdx.x][E::VEC + j] = sgx[j]; }
     __syncthreads();
