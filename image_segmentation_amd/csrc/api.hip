@@ -170,6 +170,9 @@ int segk_convt2x2_fwd(const void* in, const void* wpacked, const float* bias4, v
                       int Cout, int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "convt2x2_fwd: bad dtype %d", dtype);
   // bias4: per-N bias of length 4*Cout (the layer bias repeated for the four taps) or NULL
+  SEGK_REQUIRE(in && wpacked && out && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "convt2x2_fwd: bad arguments");
+  if (segk_convt_stream_ok(B, H, W, Cin, Cout, dtype))      // short K: weights in registers, no LDS, no unit boundary
+    return segk_convt_stream_launch(in, wpacked, bias4, out, B, H, W, Cin, Cout, (hipStream_t)s);
   ConvArgs a{};
   a.srcA = in; a.w = wpacked; a.bias = bias4; a.out = out;
   a.B = B; a.H = H; a.W = W; a.CA = Cin; a.Ntot = 4 * Cout; a.CO1 = Cout; a.shuffle = 1;

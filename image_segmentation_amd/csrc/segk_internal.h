@@ -35,6 +35,10 @@ int segk_conv_use_rs(int cin_p, int n_p, int dtype, int W);
 int segk_conv_rs_rows(int B, int H, int W, int n_p);          // rows of BatchNorm partials it writes
 void segk_conv_rs_grid(int B, int H, int W, int NT, int* gw_out, int* GW_out);
 int segk_conv_rs_launch(const ConvArgs& a, hipStream_t st);
+// register-stationary streaming kernel for the short-K ConvTranspose forward (convt_stream.hip)
+int segk_convt_stream_ok(int B, int H, int W, int Cin, int Cout, int dtype);
+int segk_convt_stream_launch(const void* x, const void* wp, const float* bias4, void* out, int B, int H, int W, int Cin,
+                             int Cout, hipStream_t st);
 int segk_conv_use_ws(int cin_p, int n_p, int dtype);   // weight-stationary variant applies
 int segk_conv_use_pipe(int cin_p, int n_p, int dtype); // producer/consumer variant: its channel tile (128 | 64) or 0
 int segk_conv_writes_act(int cin_p, int n_p, int dtype); // the layer's kernel can emit ConvArgs::act_out

@@ -389,11 +389,13 @@ def test_confusion(ops):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 128, 64, 16, 16), (1, 64, 32, 8, 8), (2, 256, 128, 12, 20), (1, 96, 64, 16, 16),
-                                  (3, 64, 128, 10, 14)])
+                                  (3, 64, 128, 10, 14), (1, 256, 128, 8, 32), (2, 128, 64, 5, 48), (1, 128, 32, 4, 16),
+                                  (1, 256, 64, 3, 16), (3, 128, 128, 7, 32)])
 def test_convt2x2_forward_and_data_gradient(ops, dtype, case):
     """ConvTranspose2d(k=2,s=2) as GEMM + pixel-shuffle store and its data gradient as an un-shuffle gather GEMM
-    (reference unet/unet.py:59): the long-K shapes run the producer/consumer GEMM (gemm.hip), short or ragged ones the
-    generic streaming kernel; both against F.conv_transpose2d / its autograd."""
+    (reference unet/unet.py:59): the long-K shapes run the producer/consumer GEMM (gemm.hip), bf16 with Cin 128 / 256 and
+    whole 16-pixel blocks per row the register-stationary streaming kernel (convt_stream.hip: all of its wave layouts are
+    among the cases), the rest the generic kernel; all against F.conv_transpose2d / its autograd."""
     from image_segmentation_amd import _lib
     B, Cin, Cout, H, W = case
     x0 = fill((B, Cin, H, W), 1, -1, 1).to(dtype).float()
