@@ -118,6 +118,13 @@ int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const 
 
 int segk_conv_writes_act_q(int Cin, int Cout, int dtype) { return segk_conv_writes_act(Cin, Cout, dtype); }
 
+int segk_stem3x3_rows(int B, int H, int W, int Cin, int Cout, int dtype) { return segk_stem_rows(B, H, W, Cin, Cout, dtype); }
+int segk_stem3x3(const float* x_nchw, const float* w_oihw, void* z, void* x_nhwc, float* stats, int B, int H, int W, int Cin,
+                 int Cout, int dtype, segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_BF16, "stem3x3: bf16 only (dtype %d)", dtype);
+  return segk_stem_launch(x_nchw, w_oihw, z, x_nhwc, stats, B, H, W, Cin, Cout, (hipStream_t)s);
+}
+
 int segk_conv3x3_act(const void* srcA, const void* wpacked, const float* scale, const float* shift, void* out,
                      void* act_out, float* stats, int B, int H, int W, int CA, int CO, int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "conv3x3_act: bad dtype %d", dtype);

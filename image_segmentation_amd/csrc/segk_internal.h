@@ -35,6 +35,10 @@ int segk_conv_use_rs(int cin_p, int n_p, int dtype, int W);
 int segk_conv_rs_rows(int B, int H, int W, int n_p);          // rows of BatchNorm partials it writes
 void segk_conv_rs_grid(int B, int H, int W, int NT, int* gw_out, int* GW_out);
 int segk_conv_rs_launch(const ConvArgs& a, hipStream_t st);
+// the U-Net stem on the NCHW fp32 input (stem.hip)
+int segk_stem_rows(int B, int H, int W, int Cin, int Cout, int dtype);
+int segk_stem_launch(const float* x, const float* w, void* z, void* xn, float* stats, int B, int H, int W, int Cin, int Cout,
+                     hipStream_t st);
 // register-stationary streaming kernel for the short-K ConvTranspose forward (convt_stream.hip)
 int segk_convt_stream_ok(int B, int H, int W, int Cin, int Cout, int dtype);
 int segk_convt_stream_launch(const void* x, const void* wp, const float* bias4, void* out, int B, int H, int W, int Cin,

@@ -1,0 +1,170 @@
+// The U-Net stem: Conv2d(Cin <= 3, 64, k=3, p=1) of reference unet/unet.py:16 applied to the NCHW fp32 input batch
+// (utils/training.py:45), bf16.  The general 3x3 kernels see this layer as Cin padded to 32 channels behind a layout pass
+// (NCHW fp32 -> NHWC bf16, 134 MB written and read again) and spend 29/32 of their matrix work on zeros: 59 + 105 us.
+// Its real shape is an im2col GEMM with K = 9 Cin <= 27: ONE 16x16x32 MFMA per 16 pixels and 16 channels.
+//
+// Here a wave streams 16-pixel blocks with no LDS and no barrier: the weights of all 64 output channels for the whole K
+// are 16 registers (read once from the fp32 OIHW parameter, whose row IS the im2col order k = ci * 9 + tap, and rounded to
+// bf16 exactly like the packed copies); the B operand is gathered straight from the NCHW fp32 image -- lane (pixel, k
+// block) fetches its eight (channel, tap) values with bounds checks (neighbouring lanes and taps hit the same cache lines)
+// and rounds them to bf16, the same values the layout pass would have produced; 4 MFMAs; the result leaves from the
+// accumulators with the channel rows of each pair of 16-channel blocks interleaved, so a lane stores 8 consecutive channels
+// of its pixel (16 bytes).  BatchNorm statistics stay in registers for the whole kernel (one partial row per workgroup).
+// The padded NHWC bf16 copy of the input that the weight-gradient pass reads is written on the way (side output).
+#include <stdlib.h>
+#include "common.hpp"
+#include "segk_internal.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+  return v + __int_as_float(x);
+}
+// sum over the 16 lanes of a DPP row, result in every lane: xor 1, xor 2 (quad permutes), half mirror, mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+constexpr int STEM_WAVES = 8;
+
+__global__ __launch_bounds__(STEM_WAVES * 64, 4) void stem_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                         bf16_t* __restrict__ z, bf16_t* __restrict__ xn,
+                                                                         float* __restrict__ stats, int B, int H, int W,
+                                                                         int Cin, long nblk) {
+  __shared__ float red[STEM_WAVES][64][2];
+  const int lane = threadIdx.x & 63, lc = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = Cin * 9;
+  const long HW = (long)H * W;
+
+  // ---- weights: A operand rows = channels (pairs of 16-channel blocks interleaved), lane (row lc, k block lq)
+  u32x4 wf[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int p = g >> 1, half = g & 1;
+    const int n_row = p * 32 + 8 * (lc >> 2) + 4 * half + (lc & 3);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = lq * 8 + e;
+      f[e] = k < K ? w[(size_t)n_row * K + k] : 0.f;
+    }
+    wf[g] = (u32x4){pk_bf16(f[0], f[1]), pk_bf16(f[2], f[3]), pk_bf16(f[4], f[5]), pk_bf16(f[6], f[7])};
+  }
+  // ---- the lane's eight (channel, tap) gathers: offset from the pixel's own element of channel 0, and (dy, dx)
+  int goff[8], gdy[8], gdx[8];
+  unsigned kmask = 0;                              // bit e: k = 8 lq + e is a real (channel, tap), not K padding
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = lq * 8 + e;
+    const int ci = k / 9, tap = k - ci * 9;
+    kmask |= (k < K ? 1u : 0u) << e;
+    gdy[e] = tap / 3 - 1;
+    gdx[e] = tap % 3 - 1;
+    goff[e] = k < K ? (int)(ci * HW) + gdy[e] * W + gdx[e] : 0;
+  }
+
+  float s1[2][8], s2[2][8];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[p][j] = 0.f; s2[p][j] = 0.f; }
+
+  const int W16 = W / 16;
+  const long step = (long)gridDim.x * STEM_WAVES;
+  for (long blk = (long)blockIdx.x * STEM_WAVES + wave; blk < nblk; blk += step) {
+    const long row = blk / W16;                    // b * H + y
+    const int xx = (int)(blk - row * W16) * 16 + lc;
+    const long b = row / H;
+    const int y = (int)(row - b * H);
+    const float* px = x + (size_t)b * Cin * HW + (size_t)y * W + xx;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = ((kmask >> e) & 1u) & ((unsigned)(y + gdy[e]) < (unsigned)H) & ((unsigned)(xx + gdx[e]) < (unsigned)W);
+      v[e] = ok ? px[goff[e]] : 0.f;
+    }
+    const u32x4 bf = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[g]), __builtin_bit_cast(bf16x8, bf),
+                                                       (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    const size_t opix = (size_t)row * W + xx;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f32x4 a0 = acc[2 * p], a1 = acc[2 * p + 1];
+      const float o[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[p][j] += o[j]; s2[p][j] = fmaf(o[j], o[j], s2[p][j]); }
+      const u32x4 ov = {pk_bf16(o[0], o[1]), pk_bf16(o[2], o[3]), pk_bf16(o[4], o[5]), pk_bf16(o[6], o[7])};
+      *(u32x4*)(z + opix * 64 + p * 32 + lq * 8) = ov;
+    }
+    if (xn != nullptr) {                           // padded NHWC copy of the input (32 channels: Cin real, zeros behind)
+      u32x4 c = {0u, 0u, 0u, 0u};
+      if (lq == 0) {
+        const float c0 = px[0], c1 = Cin > 1 ? px[HW] : 0.f, c2 = Cin > 2 ? px[2 * HW] : 0.f;
+        c.x = pk_bf16(c0, c1);
+        c.y = pk_bf16(c2, 0.f);
+      }
+      *(u32x4*)(xn + opix * 32 + lq * 8) = c;
+    }
+  }
+  if (stats == nullptr) return;
+  // ---- statistics: over the 16 pixel lanes of each DPP row, then over the workgroup's waves in wave order (bit-stable)
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = row16_sum(s1[p][j]), q = row16_sum(s2[p][j]);
+      if (lc == 0) {
+        red[wave][p * 32 + lq * 8 + j][0] = a;
+        red[wave][p * 32 + lq * 8 + j][1] = q;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < STEM_WAVES; ++wv) { a += red[wv][threadIdx.x][0]; q += red[wv][threadIdx.x][1]; }
+    ((float2*)stats)[(size_t)blockIdx.x * 64 + threadIdx.x] = make_float2(a, q);
+  }
+}
+
+}  // namespace
+
+// workgroups (= rows of BatchNorm partials) of the stem kernel for this problem, or 0 where it does not apply
+int segk_stem_rows(int B, int H, int W, int Cin, int Cout, int dtype) {
+  static const bool off = getenv("SEGK_NO_STEM") != nullptr;            // A/B switch
+  if (off || dtype != SEGK_DT_BF16 || B <= 0 || H <= 0 || W <= 0 || W % 16 != 0 || Cin < 1 || Cin > 3 || Cout != 64) return 0;
+  if ((long long)B * H * W * 64 >= 2147483647LL * 16 || (long long)Cin * H * W >= 2147483647LL) return 0;
+  const long nblk = (long)B * H * (W / 16);
+  long g = (nblk + STEM_WAVES - 1) / STEM_WAVES;
+  const long cap = (long)segk_num_cus() * 2;       // two 8-wave workgroups per CU (four waves per SIMD: the gathers want many in flight)
+  if (g > cap) g = cap;
+  return (int)(g > 1024 ? 1024 : g);               // <= 1024 rows: the one-block statistics finalisation
+}
+
+int segk_stem_launch(const float* x, const float* w, void* z, void* xn, float* stats, int B, int H, int W, int Cin, int Cout,
+                     hipStream_t st) {
+  SEGK_REQUIRE(x && w && z, "stem3x3: null pointer");
+  const int g = segk_stem_rows(B, H, W, Cin, Cout, SEGK_DT_BF16);
+  SEGK_REQUIRE(g > 0, "stem3x3: shape not served (bf16, 1..3 input channels, 64 output channels, W a multiple of 16)");
+  const long nblk = (long)B * H * (W / 16);
+  hipLaunchKernelGGL(stem_stream_kernel, dim3(g), dim3(STEM_WAVES * 64), 0, st, x, w, (bf16_t*)z, (bf16_t*)xn, stats, B, H, W, Cin,
+                     nblk);
+  SEGK_CHECK_LAUNCH("stem3x3");
+  return 0;
+}

@@ -727,9 +727,21 @@ class DoubleConvFn(torch.autograd.Function):
         Coutp = pad32(Cout)
         training = mod.training
         bn1, bn2 = mod.bn_modules()
-        xa_t, pA, CAp = _raw(xa, dtype)
-        xb_t, pB, CBp = (None, 0, 0) if xb is None else _raw(xb, dtype)
         want_grad = any(ctx.needs_input_grad)
+        # the stem (reference unet.py:16 on the NCHW fp32 batch of training.py:45): a kernel of its own gathers the im2col
+        # operand straight from the image -- no layout pass, no 32-channel padding in the matrix work (segk_stem3x3)
+        stem_rows = 0
+        if (xb is None and act_info(xa, dtype) is None and xa.dtype == torch.float32 and xa.is_contiguous()
+                and w1.dtype == torch.float32 and w1.is_contiguous()):
+            stem_rows = _lib.query("segk_stem3x3_rows", B, H, W, CA, Cout, _DT[dtype])
+        if stem_rows:
+            xa_t, pA, CAp = None, 0, pad32(CA)
+            if want_grad:                            # the weight gradient reads the padded NHWC copy: written on the way
+                xbuf = torch.empty((B, H, W, CAp), dtype=dtype, device=dev)
+                xa_t, pA = act_view(xbuf, CA), xbuf.data_ptr()
+        else:
+            xa_t, pA, CAp = _raw(xa, dtype)
+        xb_t, pB, CBp = (None, 0, 0) if xb is None else _raw(xb, dtype)
         if training and want_grad:     # a backward will follow: both layouts in one pass per weight
             w1p = mod.cache.get_pair(("w1f", dtype), ("w1d", dtype), w1, lambda: pack_conv_both(w1, CA, CB, dtype),
                                      meta=(0, CA, CB, dtype))
@@ -738,13 +750,19 @@ class DoubleConvFn(torch.autograd.Function):
         else:
             w1p = mod.cache.get(("w1f", dtype), w1, lambda: pack_conv(w1, CA, CB, dtype, 0))
             w2p = mod.cache.get(("w2f", dtype), w2, lambda: pack_conv(w2, Cout, 0, dtype, 0))
-        tiles1 = _lib.query("segk_conv_tiles", B, H, W, CAp + CBp, Coutp, _DT[dtype])
+        tiles1 = stem_rows or _lib.query("segk_conv_tiles", B, H, W, CAp + CBp, Coutp, _DT[dtype])
         tiles2 = _lib.query("segk_conv_tiles", B, H, W, Coutp, Coutp, _DT[dtype])
         P = B * H * W
 
         z1 = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         st1 = _f32(_lib.query("segk_bn_stats_floats", tiles1, Coutp), dev) if training else None
-        conv3x3(xa_t, pA, CAp, pB, CBp, w1p, z1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, stats=st1, alg=(CA + CB, Cout))
+        if stem_rows:
+            e = _es(dtype)
+            with _span("conv3x3_igemm", 2.0 * P * 9 * CA * Cout, P * (4 * CA + Cout * e) + 9.0 * CA * Cout * 4):
+                _lib.call("segk_stem3x3", xa.data_ptr(), w1.data_ptr(), z1.data_ptr(), pA, _p(st1), B, H, W, CA, Cout,
+                          _DT[dtype], _stream())
+        else:
+            conv3x3(xa_t, pA, CAp, pB, CBp, w1p, z1.data_ptr(), Coutp, 0, 0, B, H, W, dtype, stats=st1, alg=(CA + CB, Cout))
         sc1, sh1, mu1, rs1 = bn_finalize(st1, tiles1, Cout, P, None if b1 is None else _param_f32(b1), _param_f32(g1),
                                          _param_f32(be1), bn1.running_mean, bn1.running_var, _bn_momentum(bn1), bn1.eps,
                                          training, dev)

@@ -78,6 +78,17 @@ int segk_pack_convt_weight(const float* w, void* dst, int Cin, int Cout, int Cin
 int segk_conv_writes_act_q(int Cin, int Cout, int dtype);
 int segk_conv3x3_act(const void* srcA, const void* wpacked, const float* scale, const float* shift, void* out,
                      void* act_out, float* stats, int B, int H, int W, int CA, int CO, int dtype, segk_stream_t s);
+
+/* The stem: Conv2d(Cin <= 3, 64, k=3, p=1) (unet/unet.py:16, first conv of down1) applied directly to the NCHW fp32 input
+ * batch of utils/training.py:45 -- an im2col GEMM with K = 9 Cin <= 27 (one MFMA step), bf16 operands rounded exactly as the
+ * layout pass + packed weights would round them, bias-free like segk_conv3x3.  x_nchw [B,Cin,H,W] fp32, w_oihw the fp32
+ * parameter itself [64][Cin][3][3]; z NHWC bf16 [B,H,W,64]; stats (may be NULL): segk_stem3x3_rows() rows of [64][2]
+ * partial sums for segk_bn_finalize; x_nhwc (may be NULL): the padded NHWC bf16 copy of the input [B,H,W,32] the
+ * weight-gradient pass reads (what segk_nchw_to_nhwc would have written).  segk_stem3x3_rows() is 0 where the kernel does
+ * not apply (bf16 only, W % 16 == 0, Cout == 64): use segk_nchw_to_nhwc + segk_conv3x3 there. */
+int segk_stem3x3_rows(int B, int H, int W, int Cin, int Cout, int dtype);
+int segk_stem3x3(const float* x_nchw, const float* w_oihw, void* z, void* x_nhwc, float* stats, int B, int H, int W, int Cin,
+                 int Cout, int dtype, segk_stream_t s);
 int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype);   /* padded CA+CB and CO1+CO2 of the call */
 /* floats to allocate for `stats`: the [tiles][Cp][2] partials plus the scratch segk_bn_finalize reduces through */
 int segk_bn_stats_floats(int tiles, int Cp);

@@ -517,3 +517,34 @@ def test_bn_relu_apply_with_pool_is_bit_identical(ops, dtype, case):
     y1 = torch.empty_like(z); p1 = torch.empty_like(p0)
     _lib.call("segk_bn_relu_apply_pool", z.data_ptr(), y1.data_ptr(), p1.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, H, W, C, dt, s)
     assert torch.equal(y0, y1) and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("case", [(2, 3, 16, 32), (1, 3, 9, 16), (3, 1, 5, 48), (2, 2, 33, 16), (1, 3, 64, 64)])
+def test_stem_conv_on_nchw_input(ops, case):
+    """segk_stem3x3 (bf16): Conv2d(Cin <= 3, 64, 3, padding=1) straight from the NCHW fp32 batch (reference unet/unet.py:16
+    on the tensor of utils/training.py:45) against F.conv2d on the bf16-rounded operands; the BatchNorm partial rows sum to
+    the statistics of the fp32 result; the padded NHWC side output equals segk_nchw_to_nhwc's bit for bit."""
+    from image_segmentation_amd import _lib
+    dtype = torch.bfloat16
+    B, Cin, H, W = case
+    x = fill((B, Cin, H, W), 1, -1, 1); w = fill((64, Cin, 3, 3), 2, -1, 1) / np.sqrt(9 * Cin)
+    rows = _lib.query("segk_stem3x3_rows", B, H, W, Cin, 64, ops._DT[dtype])
+    assert rows > 0
+    assert _lib.query("segk_stem3x3_rows", B, H, W + 1, Cin, 64, ops._DT[dtype]) == 0
+    assert _lib.query("segk_stem3x3_rows", B, H, W, 4, 64, ops._DT[dtype]) == 0
+    xd, wd = dev(x), dev(w)
+    z = torch.empty((B, H, W, 64), dtype=dtype, device="cuda")
+    xn = torch.full((B, H, W, 32), 7.0, dtype=dtype, device="cuda")
+    st = torch.full((_lib.query("segk_bn_stats_floats", rows, 64),), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.call("segk_stem3x3", xd.data_ptr(), wd.data_ptr(), z.data_ptr(), xn.data_ptr(), st.data_ptr(), B, H, W, Cin, 64,
+              ops._DT[dtype], torch.cuda.current_stream().cuda_stream)
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), padding=1)
+    got = back(z.permute(0, 3, 1, 2))
+    assert (got - ref).abs().max().item() < tol(dtype, 1) * 2
+    want = ops.to_act(xd, dtype)                                   # segk_nchw_to_nhwc: logical [B,Cin,H,W] view of NHWC
+    assert ops.act_info(want, dtype)[1] == 32
+    assert torch.equal(xn[..., :Cin], want.permute(0, 2, 3, 1))
+    assert xn[..., Cin:].abs().max().item() == 0
+    s = st[:rows * 64 * 2].view(rows, 64, 2).double().sum(0).cpu()
+    assert torch.allclose(s[:, 0], ref.double().sum(dim=(0, 2, 3)), rtol=2e-4, atol=2e-3 * np.sqrt(B * H * W))
+    assert torch.allclose(s[:, 1], (ref.double() ** 2).sum(dim=(0, 2, 3)), rtol=2e-4, atol=1e-3)

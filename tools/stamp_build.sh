@@ -5,7 +5,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/image_segmentation_amd/csrc
 mkdir -p $R/tools/ubench/bin/stamp_obj
-for f in api conv_igemm conv_rs convt_stream wgrad bn_pool pack head_loss resize vit gemm; do
+for f in api conv_igemm conv_rs convt_stream stem wgrad bn_pool pack head_loss resize vit gemm; do
   if [ "$f" = conv_rs ]; then X="-DSEGK_RS_STAMPS ${RS_ABL:+-DRS_ABL=$RS_ABL} ${RS_EXTRA}";
   elif [ "$f" = conv_igemm ]; then X="-DSEGK_PIPE_STAMPS ${PIPE_EXTRA}";
   elif [ "$f" = bn_pool ]; then X="${POOL_EXTRA}"; else X=""; fi
