@@ -33,6 +33,8 @@ SIGNATURES = {
     "segk_conv3x3_act": (_i, [_vp, _vp, _fp, _fp, _vp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_stem3x3_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "segk_stem3x3": (_i, [_fp, _fp, _vp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_stem3x3_wgrad_slabs": (_i, [_i, _i, _i, _i, _i, _i]),
+    "segk_stem3x3_wgrad": (_i, [_fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_conv1x1": (_i, [_vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_convt2x2_fwd": (_i, [_vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_convt2x2_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -119,6 +119,14 @@ int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const 
 int segk_conv_writes_act_q(int Cin, int Cout, int dtype) { return segk_conv_writes_act(Cin, Cout, dtype); }
 
 int segk_stem3x3_rows(int B, int H, int W, int Cin, int Cout, int dtype) { return segk_stem_rows(B, H, W, Cin, Cout, dtype); }
+int segk_stem3x3_wgrad_slabs(int B, int H, int W, int Cin, int Cout, int dtype) {
+  return segk_stem_wgrad_slabs(B, H, W, Cin, Cout, dtype);
+}
+int segk_stem3x3_wgrad(const float* x_nchw, const void* dz, float* slabs, int B, int H, int W, int Cin, int Cout, int dtype,
+                       segk_stream_t s) {
+  SEGK_REQUIRE(dtype == SEGK_DT_BF16, "stem3x3_wgrad: bf16 only (dtype %d)", dtype);
+  return segk_stem_wgrad_launch(x_nchw, dz, slabs, B, H, W, Cin, Cout, (hipStream_t)s);
+}
 int segk_stem3x3(const float* x_nchw, const float* w_oihw, void* z, void* x_nhwc, float* stats, int B, int H, int W, int Cin,
                  int Cout, int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dtype == SEGK_DT_BF16, "stem3x3: bf16 only (dtype %d)", dtype);

@@ -39,6 +39,9 @@ int segk_conv_rs_launch(const ConvArgs& a, hipStream_t st);
 int segk_stem_rows(int B, int H, int W, int Cin, int Cout, int dtype);
 int segk_stem_launch(const float* x, const float* w, void* z, void* xn, float* stats, int B, int H, int W, int Cin, int Cout,
                      hipStream_t st);
+int segk_stem_wgrad_slabs(int B, int H, int W, int Cin, int Cout, int dtype);
+int segk_stem_wgrad_launch(const float* x, const void* dz, float* slabs, int B, int H, int W, int Cin, int Cout,
+                           hipStream_t st);
 // register-stationary streaming kernel for the short-K ConvTranspose forward (convt_stream.hip)
 int segk_convt_stream_ok(int B, int H, int W, int Cin, int Cout, int dtype);
 int segk_convt_stream_launch(const void* x, const void* wp, const float* bias4, void* out, int B, int H, int W, int Cin,

@@ -143,7 +143,152 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 4) void stem_stream_kernel(const f
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The stem's weight gradient, dW[n][k] = sum over pixels of dz[p][n] * col[p][k] with k = ci * 9 + tap the im2col index
+// (the OIHW order of the parameter): a [64 x P] . [P x 27] contraction over PIXELS.  The general kernel runs it on the
+// 32-channel-padded NHWC copy of the input (455 MB of traffic with the halo, 9 taps x MFMAs on 29 zero channels: 100 us);
+// here a wave streams 16-pixel steps: its 16 x 64 dz values go through a 2 KB wave-private LDS slot and come back
+// transposed (ds_read_b64_tr_b16: 8 consecutive pixels of one channel per lane), the im2col operand is gathered straight
+// from the NCHW fp32 image (8 consecutive x positions of one (channel, tap) = 32 contiguous bytes per lane), two
+// 32x32x16 MFMAs per step accumulate the whole 64 x 32 gradient in 32 registers; the eight waves of a workgroup add up
+// through LDS in a fixed order and write one slab per workgroup for segk_wgrad_reduce (taps = 1, CA = 9 Cin).
+struct __attribute__((packed, aligned(4))) F4U { float v[4]; };    // 16-byte load at 4-byte alignment
+
+__global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dz,
+                                                                        float* __restrict__ slabs, int B, int H, int W, int Cin,
+                                                                        long nblk) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * 64 * 32 * 4];       // 32 KB: dz slots (2 KB per wave), then the reduction
+  typedef __attribute__((address_space(3))) s16x4* lds_v4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = Cin * 9;
+  const long HW = (long)H * W;
+  char* const slot = lds + wave * 2048;
+
+  // B operand (im2col): lane (column j = lane % 32, pixel half hh = lane / 32)
+  const int j = lane & 31, hh = lane >> 5;
+  const int ci = j / 9, tap = j - ci * 9;
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const bool jok = j < K;
+  // A operand (dz transposed): the fragment addressing of wgrad_kernel (two transposing reads per 32-channel block)
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int coff = (16 * (g & 1) + 4 * p) * 2, xa = 8 * (g >> 1) + q;
+  // dz staging: lane -> (pixel lp, 16-byte piece lc4) of each 32-channel block
+  const int lp = lane >> 2, lc4 = lane & 3;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nh][r] = 0.f;
+
+  const int W16 = W / 16;
+  const long step = (long)gridDim.x * STEM_WAVES;
+  for (long blk = (long)blockIdx.x * STEM_WAVES + wave; blk < nblk; blk += step) {
+    const long row = blk / W16;                    // b * H + y
+    const int x0 = (int)(blk - row * W16) * 16;
+    const long b = row / H;
+    const int y = (int)(row - b * H);
+    // ---- dz: 16 pixels x 64 channels -> LDS, natural [block][pixel][64 B]
+    const bf16_t* dp = dz + ((size_t)row * W + x0 + lp) * 64 + lc4 * 8;
+    const uint4 d0 = *(const uint4*)dp, d1 = *(const uint4*)(dp + 32);
+    // ---- im2col column j, pixels x0 + 8 hh .. + 7 of image row y + dy
+    float v[8];
+    const int xs = x0 + 8 * hh + dx;
+    const bool rok = jok & ((unsigned)(y + dy) < (unsigned)H);
+    const float* src = x + ((size_t)(b * Cin + ci) * H + (y + dy)) * W + xs;
+    if (rok && xs >= 0 && xs + 8 <= W) {
+      const F4U a = *(const F4U*)src, c = *(const F4U*)(src + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = a.v[e]; v[4 + e] = c.v[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (rok && (unsigned)(xs + e) < (unsigned)W) ? src[e] : 0.f;
+    }
+    *(uint4*)(slot + lp * 64 + lc4 * 16) = d0;
+    *(uint4*)(slot + 1024 + lp * 64 + lc4 * 16) = d1;
+    const u32x4 fbv = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+    const bf16x8 fb = __builtin_bit_cast(bf16x8, fbv);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // the wave's own LDS stores before its transposing reads
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(slot + nh * 1024 + xa * 64 + coff));
+      const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(slot + nh * 1024 + (xa + 4) * 64 + coff));
+      const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+      acc[nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[nh], 0, 0, 0);
+    }
+  }
+
+  // ---- the eight waves add up in a fixed order: 7..4 -> 3..0, 3..2 -> 1..0, 1 -> 0 (32 KB of LDS: four wave images)
+  float* const red = (float*)lds;
+  const int col = lane & 31, lh = lane >> 5;
+  auto put = [&](int slot_i) {
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 32 * nh + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        red[(slot_i * 64 + n) * 32 + col] = acc[nh][r];
+      }
+  };
+  auto add = [&](int slot_i) {
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 32 * nh + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        acc[nh][r] += red[(slot_i * 64 + n) * 32 + col];
+      }
+  };
+  __syncthreads();                                 // every wave is done with its dz slot
+  if (wave >= 4) put(wave - 4);
+  __syncthreads();
+  if (wave < 4) add(wave);
+  __syncthreads();
+  if (wave == 2 || wave == 3) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) add(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave == 0) {
+    add(0);
+    float* const slab = slabs + (size_t)blockIdx.x * 64 * 32;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 32 * nh + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        slab[n * 32 + col] = acc[nh][r];
+      }
+  }
+}
+
 }  // namespace
+
+// workgroups (= slabs [64][32] fp32) of the stem weight-gradient kernel, or 0 where it does not apply
+int segk_stem_wgrad_slabs(int B, int H, int W, int Cin, int Cout, int dtype) {
+  static const bool off = getenv("SEGK_NO_STEM_WGRAD") != nullptr;      // A/B switch
+  if (off) return 0;
+  const int rows = segk_stem_rows(B, H, W, Cin, Cout, dtype);           // the same shape conditions as the forward
+  if (rows <= 0) return 0;
+  const long nblk = (long)B * H * (W / 16);
+  long g = (nblk + STEM_WAVES - 1) / STEM_WAVES;
+  const long cap = (long)segk_num_cus() * 2;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+int segk_stem_wgrad_launch(const float* x, const void* dz, float* slabs, int B, int H, int W, int Cin, int Cout,
+                           hipStream_t st) {
+  SEGK_REQUIRE(x && dz && slabs, "stem_wgrad: null pointer");
+  const int g = segk_stem_wgrad_slabs(B, H, W, Cin, Cout, SEGK_DT_BF16);
+  SEGK_REQUIRE(g > 0, "stem_wgrad: shape not served (bf16, 1..3 input channels, 64 output channels, W a multiple of 16)");
+  const long nblk = (long)B * H * (W / 16);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(g), dim3(STEM_WAVES * 64), 0, st, x, (const bf16_t*)dz, slabs, B, H, W, Cin, nblk);
+  SEGK_CHECK_LAUNCH("stem_wgrad");
+  return 0;
+}
 
 // workgroups (= rows of BatchNorm partials) of the stem kernel for this problem, or 0 where it does not apply
 int segk_stem_rows(int B, int H, int W, int Cin, int Cout, int dtype) {

@@ -734,9 +734,12 @@ class DoubleConvFn(torch.autograd.Function):
         if (xb is None and act_info(xa, dtype) is None and xa.dtype == torch.float32 and xa.is_contiguous()
                 and w1.dtype == torch.float32 and w1.is_contiguous()):
             stem_rows = _lib.query("segk_stem3x3_rows", B, H, W, CA, Cout, _DT[dtype])
+        stem_raw = False
         if stem_rows:
             xa_t, pA, CAp = None, 0, pad32(CA)
-            if want_grad:                            # the weight gradient reads the padded NHWC copy: written on the way
+            if want_grad and _lib.query("segk_stem3x3_wgrad_slabs", B, H, W, CA, Cout, _DT[dtype]):
+                xa_t, stem_raw = xa.detach(), True   # the weight gradient gathers from the NCHW batch too: nothing to keep
+            elif want_grad:                          # the weight gradient reads the padded NHWC copy: written on the way
                 xbuf = torch.empty((B, H, W, CAp), dtype=dtype, device=dev)
                 xa_t, pA = act_view(xbuf, CA), xbuf.data_ptr()
         else:
@@ -814,6 +817,7 @@ class DoubleConvFn(torch.autograd.Function):
         ctx.up_dims = up_dims
         ctx.has_head = head_w is not None
         ctx.head_on_z = head_on_z
+        ctx.stem_raw = stem_raw
         ctx.save_for_backward(xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2, a1,
                               y if (cfg.emit_pool or head_w is not None) else None, up_t, up_w, head_w)
         if logits is not None:
@@ -832,7 +836,7 @@ class DoubleConvFn(torch.autograd.Function):
         dev = z1.device
         Coutp, CAp, CBp = pad32(Cout), pad32(CA), (pad32(CB) if CB else 0)
         P = B * H * W
-        pA = act_info(xa_t, dtype)[0]
+        pA = 0 if ctx.stem_raw else act_info(xa_t, dtype)[0]
         pB = 0 if xb_t is None else act_info(xb_t, dtype)[0]
         need = ctx.needs_input_grad
 
@@ -915,8 +919,16 @@ class DoubleConvFn(torch.autograd.Function):
             if has_up:
                 part = std[:tiles_d * (CAp + CBp) * 2].view(tiles_d, CAp + CBp, 2)
                 chan_sum = part[:, CAp:CAp + CB, 0].sum(dim=0)
-        slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev, alg=(Cout, CA + CB))
-        dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev, param=w1)
+        if ctx.stem_raw:        # the stem: im2col gather from the NCHW fp32 batch, slabs in OIHW column order (k = ci*9 + tap)
+            S = _lib.query("segk_stem3x3_wgrad_slabs", B, H, W, CA, Cout, _DT[dtype])
+            slabs = _f32(S * 64 * 32, dev)
+            with _span("wgrad3x3", 2.0 * P * 9 * CA * Cout, P * (Cout * _es(dtype) + 4 * CA) + 4.0 * 9 * CA * Cout):
+                _lib.call("segk_stem3x3_wgrad", xa_t.data_ptr(), dz1.data_ptr(), slabs.data_ptr(), B, H, W, CA, Cout,
+                          _DT[dtype], _stream())
+            dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, 9 * CA, 0, 1, dev, param=w1)
+        else:
+            slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev, alg=(Cout, CA + CB))
+            dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev, param=w1)
         del slabs
         # conv biases ahead of a batch-statistics BatchNorm have an identically zero gradient; ahead of a frozen one the
         # bias is part of the affine map: d(bias) = sum(dz) = scale * sum(g)

@@ -89,6 +89,12 @@ int segk_conv3x3_act(const void* srcA, const void* wpacked, const float* scale, 
 int segk_stem3x3_rows(int B, int H, int W, int Cin, int Cout, int dtype);
 int segk_stem3x3(const float* x_nchw, const float* w_oihw, void* z, void* x_nhwc, float* stats, int B, int H, int W, int Cin,
                  int Cout, int dtype, segk_stream_t s);
+/* ... and its weight gradient from the same NCHW fp32 batch and dz NHWC bf16 [B,H,W,64]: segk_stem3x3_wgrad_slabs() slabs of
+ * [64][32] fp32 (column k = ci * 9 + tap, the OIHW order; columns >= 9 Cin are zero), summed by
+ * segk_wgrad_reduce(slabs, S, grad, 64, 9 * Cin, 0, 64, 32, 0, 1).  0 slabs: not served (use segk_wgrad on the padded copy). */
+int segk_stem3x3_wgrad_slabs(int B, int H, int W, int Cin, int Cout, int dtype);
+int segk_stem3x3_wgrad(const float* x_nchw, const void* dz, float* slabs, int B, int H, int W, int Cin, int Cout, int dtype,
+                       segk_stream_t s);
 int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype);   /* padded CA+CB and CO1+CO2 of the call */
 /* floats to allocate for `stats`: the [tiles][Cp][2] partials plus the scratch segk_bn_finalize reduces through */
 int segk_bn_stats_floats(int tiles, int Cp);

@@ -548,3 +548,28 @@ def test_stem_conv_on_nchw_input(ops, case):
     s = st[:rows * 64 * 2].view(rows, 64, 2).double().sum(0).cpu()
     assert torch.allclose(s[:, 0], ref.double().sum(dim=(0, 2, 3)), rtol=2e-4, atol=2e-3 * np.sqrt(B * H * W))
     assert torch.allclose(s[:, 1], (ref.double() ** 2).sum(dim=(0, 2, 3)), rtol=2e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", [(2, 3, 16, 32), (1, 3, 9, 16), (3, 1, 5, 48), (2, 2, 33, 16), (1, 3, 64, 64)])
+def test_stem_weight_gradient_from_nchw_input(ops, case):
+    """segk_stem3x3_wgrad (bf16): the stem's weight gradient from the NCHW fp32 batch and dz (no padded NHWC copy of the
+    input): slabs of [64][32] in OIHW column order, summed by segk_wgrad_reduce(taps = 1, CA = 9 Cin), against autograd on
+    the bf16-rounded operands (exact products, fp32 accumulation: only the summation order differs)."""
+    from image_segmentation_amd import _lib
+    dtype = torch.bfloat16
+    B, Cin, H, W = case
+    x = fill((B, Cin, H, W), 1, -1, 1); g = fill((B, 64, H, W), 2, -1, 1).to(dtype).float()
+    w = torch.zeros((64, Cin, 3, 3), requires_grad=True)
+    F.conv2d(x.to(dtype).float(), w, padding=1).backward(g)
+    S = _lib.query("segk_stem3x3_wgrad_slabs", B, H, W, Cin, 64, ops._DT[dtype])
+    assert S > 0
+    ga = ops.to_act(dev(g), dtype); pg, Gp = ops.act_info(ga, dtype)
+    assert Gp == 64
+    xd = dev(x)
+    slabs = torch.full((S * 64 * 32,), float("nan"), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.call("segk_stem3x3_wgrad", xd.data_ptr(), pg, slabs.data_ptr(), B, H, W, Cin, 64, ops._DT[dtype], s)
+    grad = torch.empty((64, Cin, 3, 3), dtype=torch.float32, device="cuda")
+    _lib.call("segk_wgrad_reduce", slabs.data_ptr(), S, grad.data_ptr(), 64, 9 * Cin, 0, 64, 32, 0, 1, s)
+    assert (back(grad) - w.grad).abs().max() <= 1e-4 * np.sqrt(B * H * W), case
+    assert torch.isfinite(slabs).all()
