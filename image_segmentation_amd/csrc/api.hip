@@ -198,6 +198,9 @@ int segk_convt2x2_fwd(const void* in, const void* wpacked, const float* bias4, v
 int segk_convt2x2_dgrad(const void* dout, const void* wpacked, void* din, int B, int H, int W, int Cin, int Cout,
                         int dtype, segk_stream_t s) {
   SEGK_REQUIRE(dtype == SEGK_DT_F32 || dtype == SEGK_DT_BF16, "convt2x2_dgrad: bad dtype %d", dtype);
+  SEGK_REQUIRE(dout && wpacked && din && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "convt2x2_dgrad: bad arguments");
+  if (segk_convt_stream_dgrad_ok(B, H, W, Cin, Cout, dtype))
+    return segk_convt_stream_dgrad_launch(dout, wpacked, din, B, H, W, Cin, Cout, (hipStream_t)s);
   ConvArgs a{};
   a.srcA = dout; a.w = wpacked; a.out = din;
   a.B = B; a.H = H; a.W = W; a.CA = Cout; a.Ntot = Cin; a.CO1 = Cin; a.unshuf = 1;

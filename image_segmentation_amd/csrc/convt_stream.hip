@@ -20,15 +20,18 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// KS = Cin / 32 k-steps, NBW = 16-channel blocks per wave (KS * NBW = 32 fragments = 128 weight registers)
-template <int KS, int NBW>
+// KS = K / 32 k-steps, NBW = 16-channel blocks per wave (KS * NBW = 32 fragments = 128 weight registers).
+// MODE 0: forward, K = Cin, N = 4 Cout (tap-major), x [B,H,W,Cin] -> out [B,2H,2W,Cout] pixel-shuffled (+ bias4).
+// MODE 1: data gradient, K = 4 Cout (tap-major: k-step ks reads tap ks / (Cout/32) of the 2x2 output pixels of an input
+//         pixel), N = Cin: x := dout [B,2H,2W,Cout] -> out := din [B,H,W,Cin]; `Cout` is the layer's Cout in both modes.
+template <int KS, int NBW, int MODE>
 __global__ __launch_bounds__(512, 2) void convt_stream_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
                                                               const float* __restrict__ bias4, bf16_t* __restrict__ out,
                                                               int B, int H, int W, int Cout, int nblocks16) {
   constexpr int K = KS * 32;
   const int lane = threadIdx.x & 63, lc = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int N = 4 * Cout, N16 = N / 16;
+  const int N = MODE == 0 ? 4 * Cout : NBW * 16 * 2, N16 = N / 16;      // MODE 1: N = Cin = 128 (two waves cover it)
   const int wpc = N16 / NBW;                       // waves that cover all N
   const int streams = 8 / wpc;                     // independent pixel streams of the workgroup
   const int wn = wave % wpc, stream = wave / wpc;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(512, 2) void convt_stream_kernel(const bf16_t* __re
     for (int ks = 0; ks < KS; ++ks)
       wf[ks][nb] = *(const u32x4*)(wp + ((size_t)ks * N + n_row) * 32 + lq * 8);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bs[nb][j] = bias4 ? bias4[p * 32 + 8 * lq + 4 * half + j] : 0.f;   // rows 4 lq + j of D
+    for (int j = 0; j < 4; ++j) bs[nb][j] = (MODE == 0 && bias4) ? bias4[p * 32 + 8 * lq + 4 * half + j] : 0.f;   // rows 4 lq + j of D
   }
 
   const long total = (long)nblocks16;              // 16-pixel blocks: W % 16 == 0, so a block never leaves its image row
@@ -53,12 +56,26 @@ __global__ __launch_bounds__(512, 2) void convt_stream_kernel(const bf16_t* __re
   long pb = (long)blockIdx.x * streams + stream;
   if (pb >= total) return;
   u32x4 xf0[KS], xf1[KS];                          // ping-pong by code, not by index (a run-time index would put them in scratch)
-  auto load_x = [&](long blk, u32x4 (&f)[KS]) {
-    const bf16_t* src = x + ((size_t)blk * 16 + lc) * K + lq * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) f[ks] = *(const u32x4*)(src + ks * 32);
-  };
   const int W16 = W / 16;
+  auto load_x = [&](long blk, u32x4 (&f)[KS]) {
+    if constexpr (MODE == 0) {
+      const bf16_t* src = x + ((size_t)blk * 16 + lc) * K + lq * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) f[ks] = *(const u32x4*)(src + ks * 32);
+    } else {
+      const long row = blk / W16;                  // b * H + y of the INPUT grid
+      const int xi = (int)(blk - row * W16) * 16 + lc;
+      const long b = row / H;
+      const int y = (int)(row - b * H);
+      const int cpt = Cout / 32;                   // k-steps per tap
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int tap = ks / cpt, cc = ks - tap * cpt;
+        const size_t opix = ((size_t)(b * 2 * H + 2 * y + (tap >> 1))) * (2 * W) + 2 * xi + (tap & 1);
+        f[ks] = *(const u32x4*)(x + opix * Cout + cc * 32 + lq * 8);
+      }
+    }
+  };
   // one 16-pixel block: the next block's loads go out first, then K/32 x NBW MFMAs, then NBW/2 sixteen-byte stores per lane
   auto block = [&](long blk, const u32x4 (&cur)[KS], u32x4 (&nxt)[KS]) {
     if (blk + step < total) load_x(blk + step, nxt);
@@ -86,8 +103,12 @@ __global__ __launch_bounds__(512, 2) void convt_stream_kernel(const bf16_t* __re
       asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.y) : "v"(a0[2]), "v"(a0[3]));
       asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.z) : "v"(a1[0]), "v"(a1[1]));
       asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.w) : "v"(a1[2]), "v"(a1[3]));
-      const size_t opix = ((size_t)(b * 2 * H + 2 * y + (tap >> 1))) * (2 * W) + 2 * x0 + (tap & 1);
-      *(u32x4*)(out + opix * Cout + co) = v;
+      if constexpr (MODE == 0) {
+        const size_t opix = ((size_t)(b * 2 * H + 2 * y + (tap >> 1))) * (2 * W) + 2 * x0 + (tap & 1);
+        *(u32x4*)(out + opix * Cout + co) = v;
+      } else {
+        *(u32x4*)(out + ((size_t)row * W + x0) * N + n_base + 8 * lq) = v;
+      }
     }
   };
   load_x(pb, xf0);
@@ -101,15 +122,15 @@ __global__ __launch_bounds__(512, 2) void convt_stream_kernel(const bf16_t* __re
   }
 }
 
-template <int KS, int NBW>
-int launch(const void* x, const void* wp, const float* bias4, void* out, int B, int H, int W, int Cout, hipStream_t st) {
+template <int KS, int NBW, int MODE>
+int launch(const void* x, const void* wp, const float* bias4, void* out, int B, int H, int W, int Cout, int n16, hipStream_t st) {
   const long nblk = (long)B * H * (W / 16);
-  const int wpc = (4 * Cout / 16) / NBW, streams = 8 / wpc;
+  const int wpc = n16 / NBW, streams = 8 / wpc;
   long g = (nblk + streams - 1) / streams;
   const long cap = (long)segk_num_cus();           // one 8-wave workgroup per CU (two waves per SIMD at <= 256 registers)
   if (g > cap) g = cap;
-  hipLaunchKernelGGL((convt_stream_kernel<KS, NBW>), dim3((int)g), dim3(512), 0, st, (const bf16_t*)x, (const bf16_t*)wp, bias4,
-                     (bf16_t*)out, B, H, W, Cout, (int)nblk);
+  hipLaunchKernelGGL((convt_stream_kernel<KS, NBW, MODE>), dim3((int)g), dim3(512), 0, st, (const bf16_t*)x, (const bf16_t*)wp,
+                     bias4, (bf16_t*)out, B, H, W, Cout, (int)nblk);
   SEGK_CHECK_LAUNCH("convt_stream");
   return 0;
 }
@@ -133,5 +154,22 @@ int segk_convt_stream_launch(const void* x, const void* wp, const float* bias4, 
                              int Cout, hipStream_t st) {
   SEGK_REQUIRE(x && wp && out, "convt_stream: null pointer");
   SEGK_REQUIRE(segk_convt_stream_ok(B, H, W, Cin, Cout, SEGK_DT_BF16), "convt_stream: shape not served");
-  return Cin == 128 ? launch<4, 8>(x, wp, bias4, out, B, H, W, Cout, st) : launch<8, 4>(x, wp, bias4, out, B, H, W, Cout, st);
+  const int n16 = 4 * Cout / 16;
+  return Cin == 128 ? launch<4, 8, 0>(x, wp, bias4, out, B, H, W, Cout, n16, st)
+                    : launch<8, 4, 0>(x, wp, bias4, out, B, H, W, Cout, n16, st);
+}
+
+// ... and this ConvTranspose data gradient (bf16, Cin 128, Cout 64: the up4 level -- K = 4 Cout = 256, N = Cin = 128)
+int segk_convt_stream_dgrad_ok(int B, int H, int W, int Cin, int Cout, int dtype) {
+  static const bool off = getenv("SEGK_NO_CONVT_STREAM") != nullptr;
+  if (off || dtype != SEGK_DT_BF16 || B <= 0 || H <= 0 || W <= 0 || W % 16 != 0) return 0;
+  if ((long long)B * H * W * 4 >= 2147483647LL) return 0;
+  return (Cin == 128 && Cout == 64) ? 1 : 0;
+}
+
+int segk_convt_stream_dgrad_launch(const void* dout, const void* wd, void* din, int B, int H, int W, int Cin, int Cout,
+                                   hipStream_t st) {
+  SEGK_REQUIRE(dout && wd && din, "convt_stream_dgrad: null pointer");
+  SEGK_REQUIRE(segk_convt_stream_dgrad_ok(B, H, W, Cin, Cout, SEGK_DT_BF16), "convt_stream_dgrad: shape not served");
+  return launch<8, 4, 1>(dout, wd, nullptr, din, B, H, W, Cout, Cin / 16, st);
 }

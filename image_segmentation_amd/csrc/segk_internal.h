@@ -46,6 +46,9 @@ int segk_stem_wgrad_launch(const float* x, const void* dz, float* slabs, int B, 
 int segk_convt_stream_ok(int B, int H, int W, int Cin, int Cout, int dtype);
 int segk_convt_stream_launch(const void* x, const void* wp, const float* bias4, void* out, int B, int H, int W, int Cin,
                              int Cout, hipStream_t st);
+int segk_convt_stream_dgrad_ok(int B, int H, int W, int Cin, int Cout, int dtype);
+int segk_convt_stream_dgrad_launch(const void* dout, const void* wd, void* din, int B, int H, int W, int Cin, int Cout,
+                                   hipStream_t st);
 int segk_conv_use_ws(int cin_p, int n_p, int dtype);   // weight-stationary variant applies
 int segk_conv_use_pipe(int cin_p, int n_p, int dtype); // producer/consumer variant: its channel tile (128 | 64) or 0
 int segk_conv_writes_act(int cin_p, int n_p, int dtype); // the layer's kernel can emit ConvArgs::act_out
