@@ -61,6 +61,168 @@ def labels(shape, seed, num_classes):
     return torch.from_numpy(lab.reshape(shape))
 
 
+def run_workload(args, world, rank, dev, want_levels=False):
+    """Build the model of `args` (model / batch / size / dtype / loss), run args.warmup untimed and args.steps timed
+    training steps bracketed by barrier + synchronize, then args.profile_steps instrumented steps (HIP events on the launch
+    stream around every kernel family; every rank runs them -- they contain the gradient all-reduce -- rank 0 records).
+    Returns the max-over-ranks time of the timed region and the per-family (and, for the U-Net, per-level) event sums."""
+    import torch
+    import torch.distributed as dist
+    import image_segmentation_amd as seg
+    from image_segmentation_amd import ops
+    from image_segmentation_amd.parallel import GradSync
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    prev_dtype = seg.get_compute_dtype()
+    seg.set_compute_dtype(dtype)
+    B, S = args.batch, args.size
+    torch.manual_seed(1234)                       # identical random-init weights on every rank
+    ncls = 3
+    if args.model == "clipunet":
+        ncls = 4
+        model = seg.ClipUNet(num_classes=4, encoder=seg.ClipViTEncoder.from_config()).to(dev).train()
+    else:
+        model = seg.unet(3, 3).to(dev).train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], weight_decay=0.01, fused=True)
+    if args.loss == "ce":
+        loss_fn = seg.CrossEntropyLoss()
+    else:
+        cw = torch.tensor([0.2046795970925636, 1.0271954434416883, 1.2293222812780409])
+        loss_fn = seg.WeightedDiceCELoss(smooth_dice=1.0, class_weights=cw)
+    X = fill((B, 3, S, S), 1 + 2 * rank, 0, 1).to(dev)           # images resident in HBM before timing
+    Y = labels((B, S, S), 2 + 2 * rank, ncls).to(dev)
+    gs = GradSync(model) if world > 1 else None
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        if gs is not None:
+            gs.arm()
+        loss = loss_fn(model(X), Y)
+        if gs is not None:
+            gs.backward_begin()
+        loss.backward()
+        if gs is not None:
+            gs.backward_end()
+            gs.sync()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    prof, level_prof, overlap = {}, {}, None
+    if args.profile_steps > 0:
+        if rank == 0:
+            ops.TIMER = ops.KernelTimer()
+            if want_levels:
+                ops.name_levels(model)
+            if gs is not None:
+                gs.timing = True             # per-bucket launch / completion events of the last instrumented step
+        for _ in range(args.profile_steps):
+            step()
+        if rank == 0:
+            prof = ops.TIMER.summary()
+            level_prof = ops.TIMER.level_summary() if want_levels else {}
+            ops.TIMER = None
+            if gs is not None:
+                overlap = gs.overlap_trace()
+                gs.timing = False
+    if world > 1:
+        dist.barrier()
+    if gs is not None:
+        gs.remove()
+    del model, opt, X, Y
+    torch.cuda.empty_cache()
+    seg.set_compute_dtype(prev_dtype)
+    return {"dt": dt, "final_loss": final_loss, "prof": prof, "levels": level_prof, "overlap": overlap}
+
+
+def family_table(prof, n, peak):
+    """per-kernel-family ms per step, achieved TFLOP/s and algorithmic GB/s from the instrumented steps"""
+    kernels = family_table(prof, n, peak)
+    return kernels
+
+
+def two_roofs(flops, nbytes, seconds, peak):
+    """Which roof binds a kernel (or a group of kernels) with these algorithmic counts, and the fraction of it reached:
+    bound time = max(flops / MFMA peak, bytes / 8 TB/s); frac = bound time / measured time."""
+    t_m, t_h = flops / peak, nbytes / HBM_PEAK
+    bound = "mfma" if t_m >= t_h else "hbm"
+    return {"bound": bound, "frac": round(max(t_m, t_h) / seconds, 4) if seconds > 0 else None,
+            "mfma_frac": round(t_m / seconds, 4) if seconds > 0 else None,
+            "hbm_frac": round(t_h / seconds, 4) if seconds > 0 else None}
+
+
+def level_table(level_prof, n, peak):
+    """SURVEY 7 hard part 1 / 8(d): per DoubleConv level x {fwd, dgrad, wgrad} (the 3x3 conv kernels of the block, both convs
+    together) the time per step, TFLOP/s, algorithmic GB/s, which roof binds and the fraction of THAT roof; `other` = every
+    other launch of the block's autograd node (BatchNorm passes, pooling / head / ConvTranspose kernels, slab reductions)."""
+    out = {}
+    for (level, phase), r in sorted(level_prof.items()):
+        sec = r["ms"] * 1e-3 / n
+        row = {"launches": r["launches"] // n, "us": round(sec * 1e6, 1)}
+        if phase != "other" and sec > 0:
+            fl, by = r["flops"] / n, r["bytes"] / n
+            row.update({"tflops": round(fl / sec / 1e12, 1), "alg_GBps": round(by / sec / 1e9, 1)})
+            row.update(two_roofs(fl, by, sec, peak))
+        out.setdefault(level, {})[phase] = row
+    return out
+
+
+def other_configs(args, world, rank, dev):
+    """After the headline timed region: 10 timed steps each of BASELINE config 4 (CLIP-UNet, B=16, 224x224), config 5
+    (B=8, 512x512, Dice+CE) and the fp32 parity mode at config 2 -- the mode that meets the north-star parity gate --, each with
+    its dominant kernel family and that family's fraction of the roof that binds it."""
+    import copy
+    out = {}
+    for name, over in (("config4_clipunet_B16_224", {"model": "clipunet", "batch": 16, "size": 224, "loss": "ce", "dtype": "bf16"}),
+                       ("config5_unet_B8_512_dicece", {"model": "unet", "batch": 8, "size": 512, "loss": "dicece", "dtype": "bf16"}),
+                       ("config2_fp32_parity_mode", {"model": "unet", "batch": 32, "size": 256, "loss": "ce", "dtype": "f32"})):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.steps, a.warmup, a.profile_steps = 10, 3, 2
+        try:
+            w = run_workload(a, world, rank, dev)
+            peak = MFMA_PEAK[a.dtype]
+            row = {"ms_per_step": round(w["dt"] / a.steps * 1e3, 3), "value": round(a.batch * a.steps / w["dt"], 2),
+                   "unit": "images/sec", "steps": a.steps, "warmup": a.warmup, "dtype": a.dtype,
+                   "final_loss": round(w["final_loss"], 5)}
+            if w["prof"]:
+                dom = max(w["prof"], key=lambda k: w["prof"][k]["ms"])
+                r = w["prof"][dom]
+                sec = r["ms"] * 1e-3
+                row["dominant"] = {"kernel": dom, "launches_per_step": r["launches"] // a.profile_steps,
+                                   "ms_per_step": round(r["ms"] / a.profile_steps, 4),
+                                   "tflops": round(r["flops"] / sec / 1e12, 1) if sec > 0 else None,
+                                   **two_roofs(r["flops"], r["bytes"], sec, peak)}
+                vg = w["prof"].get("vit_gemm")
+                if vg and vg["ms"] > 0:
+                    row["vit_gemm"] = {"launches_per_step": vg["launches"] // a.profile_steps,
+                                       "ms_per_step": round(vg["ms"] / a.profile_steps, 4),
+                                       "tflops": round(vg["flops"] / (vg["ms"] * 1e-3) / 1e12, 1)}
+            out[name] = row
+        except Exception as e:              # an extra must never take the headline line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,7 +240,13 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to rehearse "
                     "the multi-rank code path on a box with fewer GPUs than ranks")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the blocks appended after the headline timed region "
+                    "(per-level roofline table, other BASELINE configurations, clock probe)")
     args = ap.parse_args()
+
+    # dmabuf IPC: RCCL needs it on this driver.  Set before torch is imported, for every way a rank can be started -- by
+    # the self-launch below (inherited) and by the driver's own `python -m torch.distributed.run ... bench.py` alike.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Started without a launcher: this process becomes the launcher.  It has not touched the GPU (torch is not even
@@ -91,8 +259,7 @@ def main():
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+        env = dict(os.environ)                                  # carries HSA_ENABLE_IPC_MODE_LEGACY=0 (set above)
         env.setdefault("OMP_NUM_THREADS", "8")
         # rank 0's JSON line is relayed to stdout; anything else a rank writes there (the gloo transport of the rehearsal
         # mode prints connection notes to stdout from C++) goes to stderr, so stdout carries exactly ONE line
@@ -125,76 +292,16 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    seg.set_compute_dtype(dtype)
     B, S = args.batch, args.size
-    torch.manual_seed(1234)                       # identical random-init weights on every rank
-    ncls = 3
-    if args.model == "clipunet":
-        ncls = 4
-        model = seg.ClipUNet(num_classes=4, encoder=seg.ClipViTEncoder.from_config()).to(dev).train()
-    else:
-        model = seg.unet(3, 3).to(dev).train()
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], weight_decay=0.01, fused=True)
-    if args.loss == "ce":
-        loss_fn = seg.CrossEntropyLoss()
-    else:
-        cw = torch.tensor([0.2046795970925636, 1.0271954434416883, 1.2293222812780409])
-        loss_fn = seg.WeightedDiceCELoss(smooth_dice=1.0, class_weights=cw)
-    X = fill((B, 3, S, S), 1 + 2 * rank, 0, 1).to(dev)           # images resident in HBM before timing
-    Y = labels((B, S, S), 2 + 2 * rank, ncls).to(dev)
-    gs = GradSync(model) if world > 1 else None
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        if gs is not None:
-            gs.arm()
-        loss = loss_fn(model(X), Y)
-        loss.backward()
-        if gs is not None:
-            gs.sync()
-        opt.step()
-        return loss
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    final_loss = loss.item()
+    w = run_workload(args, world, rank, dev, want_levels=(args.model == "unet" and not args.no_extras))
+    dt, final_loss, prof, level_prof, overlap = w["dt"], w["final_loss"], w["prof"], w["levels"], w["overlap"]
     me = {"rank": rank, "device": local, "name": torch.cuda.get_device_name(local)}
     ranks_info = [me]
     if world > 1:
         ranks_info = [None] * world
         dist.all_gather_object(ranks_info, me)
-    rehearsal = world > 1 and (args.backend != "nccl" or args.share_device)
-
-    # ---- instrumented pass (rank 0): per-kernel-family HIP-event timings on the launch stream
-    # Every rank runs these steps (they contain the gradient all-reduce: a rank stepping alone would dead-lock the
-    # collective); only rank 0 records events.
-    prof = {}
-    if args.profile_steps > 0:
-        if rank == 0:
-            ops.TIMER = ops.KernelTimer()
-        for _ in range(args.profile_steps):
-            step()
-        if rank == 0:
-            prof = ops.TIMER.summary()
-            ops.TIMER = None
-    if world > 1:
         dist.barrier()
+    rehearsal = world > 1 and (args.backend != "nccl" or args.share_device)
 
     if rank != 0:
         if world > 1:
@@ -203,14 +310,7 @@ def main():
 
     n = max(1, args.profile_steps)
     peak = MFMA_PEAK[args.dtype]
-    kernels = {}
-    for tag, r in prof.items():
-        ms = r["ms"] / n
-        kernels[tag] = {
-            "launches_per_step": r["launches"] // n, "ms_per_step": round(ms, 4),
-            "tflops": round(r["flops"] / n / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
-            "alg_GBps": round(r["bytes"] / n / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
-        }
+    kernels = family_table(prof, n, peak)
     roofline = None
     if prof:
         dom = max(prof, key=lambda k: prof[k]["ms"])
@@ -237,8 +337,15 @@ def main():
         # attached only to a line produced by that same build, otherwise `traffic` stays null with the reason.
         try:
             from image_segmentation_amd import _lib
-            src = "profiles/r02_pmc_traffic.json"
-            pmc = json.load(open(os.path.join(ROOT, src)))
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)   # newest round first
+            src, pmc = "profiles/(no r*_pmc_traffic.json)", {}
+            for c in cands:
+                rec = json.load(open(c))
+                if not pmc or rec.get("build_id") == _lib.build_id():
+                    src, pmc = os.path.relpath(c, ROOT), rec
+                if rec.get("build_id") == _lib.build_id():
+                    break
             fam = {"conv3x3_igemm": "conv3x3", "wgrad3x3": "wgrad3x3"}.get(dom)
             if pmc.get("build_id") != _lib.build_id():
                 roofline["traffic_note"] = (f"{src} was recorded on library build {pmc.get('build_id')}, this run is "
@@ -279,6 +386,19 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.model == "unet":
         cpu = cpu_baseline(S)
 
+    # ---- appended evidence (after the headline timed region, which stays un-instrumented): per-level two-roof table, the
+    # other BASELINE configurations and the parity mode through the same code path, and a clock estimate for this box
+    levels = level_table(level_prof, n, peak) if level_prof else None
+    extras, clock = None, None
+    headline = (args.model == "unet" and B == 32 and S == 256 and args.loss == "ce" and args.dtype == "bf16")
+    if not args.no_extras:
+        try:
+            clock = ops.clock_probe()
+        except Exception as e:
+            clock = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and headline:
+            extras = other_configs(args, world, rank, dev)
+
     out = {
         "metric": "images/sec (fwd+bwd) U-Net 3-class 256x256; IoU parity vs CPU ref" if args.model == "unet" else
                   "images/sec (frozen ViT-B/16 fwd + decoder fwd+bwd) CLIP-UNet 4-class 224x224 (BASELINE config 4, not the headline metric)",
@@ -295,6 +415,8 @@ def main():
                    "rccl_ranks": (world if (world > 1 and args.backend == "nccl") else 0),
                    "ranks": ranks_info, "rehearsal": rehearsal},
         "roofline": roofline, "cpu_baseline": cpu, "doubleconv_scope": scope, "kernels": kernels,
+        "launches_per_step": sum(k["launches_per_step"] for k in kernels.values()) if kernels else None,
+        "levels": levels, "other_configs": extras, "clock": clock, "allreduce_overlap": overlap,
     }
     print(json.dumps(out))
     if world > 1:

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsegk.so")
 
 F32, BF16 = 0, 1
+ABI_VERSION = 300          # SEGK_ABI_VERSION of the include/segk.h this table was written against
 MAX_CLASSES = 8
 
 _vp, _fp, _i, _l, _f, _d = C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
@@ -17,6 +18,8 @@ _vp, _fp, _i, _l, _f, _d = C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float,
 # name -> (restype, argtypes); mirrors include/segk.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
     "segk_version": (_i, []),
+    "segk_entry_count": (_i, []),
+    "segk_clock_probe": (_i, [_vp, _i, _i, _vp]),
     "segk_build_id": (C.c_char_p, []),
     "segk_last_error": (C.c_char_p, []),
     "segk_nchw_to_nhwc": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -99,9 +102,20 @@ def load():
                 "Build it with `python -m image_segmentation_amd.build`.")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)          # AttributeError if the .so does not export the symbol
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                raise RuntimeError(f"{LIB_PATH} does not export {name}: it was built from another include/segk.h than "
+                                   "this binding (rebuild with `python -m image_segmentation_amd.build`)") from None
             fn.restype = res
             fn.argtypes = args
+        # A library built against another header is refused (SEGK_LIB / --lib diagnostic builds included): the host sizes
+        # buffers with this table's queries, so a kernel set with other geometry rules must never run behind it
+        ver, nent = lib.segk_version(), lib.segk_entry_count()
+        if ver != ABI_VERSION or nent != len(SIGNATURES):
+            raise RuntimeError(f"{LIB_PATH}: ABI version {ver} with {nent} entries, this binding expects version "
+                               f"{ABI_VERSION} with {len(SIGNATURES)} entries -- refusing to drive a library built from "
+                               "another include/segk.h")
         _lib = lib
     return _lib
 

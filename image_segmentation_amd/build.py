@@ -9,7 +9,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["api.hip", "conv_igemm.hip", "conv_rs.hip", "convt_stream.hip", "stem.hip", "wgrad.hip", "bn_pool.hip", "pack.hip", "head_loss.hip", "resize.hip", "vit.hip", "gemm.hip"]
+SOURCES = ["api.hip", "conv_igemm.hip", "conv_rs.hip", "convt_stream.hip", "stem.hip", "wgrad.hip", "bn_pool.hip", "pack.hip", "head_loss.hip", "resize.hip", "vit.hip", "gemm.hip", "probe.hip"]
 LIB = os.path.join(CSRC, "libsegk.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 

@@ -47,6 +47,30 @@ class ClipViTEncoder(nn.Module):
         return cls(freeze_encoder=freeze_encoder, skip_indices=skip_indices,
                    _config=config or CLIPVisionConfig(patch_size=16))
 
+    @staticmethod
+    def remap_clip_keys(state_dict, own, nested):
+        """In place: bring every `<own>...` key to the layout of the installed transformers -- `<own>vision_model.<rest>`
+        (4.x: CLIPVisionModel wraps a CLIPVisionTransformer; the layout of checkpoints written by the reference,
+        clip/clipunet.py:25-26 and prompt_based/segmentation_webapp/app.py:65-79) when `nested`, `<own><rest>` (5.x)
+        otherwise.  `position_ids` buffers (persistent in old 4.x releases only) follow the same rule."""
+        vm = "vision_model."
+        for k in [k for k in state_dict if k.startswith(own)]:
+            rest = k[len(own):]
+            if nested and not rest.startswith(vm):
+                state_dict[own + vm + rest] = state_dict.pop(k)
+            elif not nested and rest.startswith(vm):
+                state_dict[own + rest[len(vm):]] = state_dict.pop(k)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        # load_state_dict works on its own shallow copy of the caller's dict, and a module's hook runs before its
+        # children are loaded: renaming here is what the `clip_vit` child then sees
+        own = prefix + "clip_vit."
+        self.remap_clip_keys(state_dict, own, hasattr(self.clip_vit, "vision_model"))
+        pid = own + ("vision_model." if hasattr(self.clip_vit, "vision_model") else "") + "embeddings.position_ids"
+        if pid in state_dict and pid[len(own):] not in self.clip_vit.state_dict():
+            del state_dict[pid]                   # saved by a release that kept the index buffer persistent
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
     def _grid(self, hidden_state, n):
         # drop CLS, [B,196,768] -> [B,768,14,14] (clipunet.py:48-51,54-63).  The permuted view of the
         # contiguous token tensor IS a channels-last [B,C,H,W] tensor: no copy is needed for the kernels.

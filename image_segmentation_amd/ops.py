@@ -9,6 +9,7 @@ dtype (fp32 = parity mode, bf16 = performance mode).  For C % 32 == 0 this is ex
 channels_last memory format.
 """
 import os
+import weakref
 
 import torch
 
@@ -116,6 +117,16 @@ def act_to_nchw(t):
     return out
 
 
+def _private_act_copy(t, dtype):
+    """A fresh NHWC buffer [B,H,W,Cp] holding the bytes of act tensor `t` (padding channels included)."""
+    ptr, Cp = act_info(t, dtype)
+    B, C, H, W = t.shape
+    n = B * H * W * Cp
+    out = torch.empty((B, H, W, Cp), dtype=dtype, device=t.device)
+    out.view(-1).copy_(torch.as_strided(t, (n,), (1,), t.storage_offset()))
+    return out
+
+
 def _raw(t, dtype):
     """(ptr, Cp) of an act tensor, converting if needed; returns (tensor_kept_alive, ptr, Cp)."""
     t = to_act(t, dtype)
@@ -128,6 +139,7 @@ def _raw(t, dtype):
 # Optimizer steps invalidate every packed copy of a trainable parameter.  The autograd version counter alone is not
 # enough: fused optimizers (torch.optim.AdamW(fused=True), torch._fused_adamw_) update parameters in place WITHOUT
 # moving `param._version`, so a global post-step hook counts optimizer steps as well.
+INPLACE_SKIP_GRAD = True   # the pooling backward accumulates into the incoming skip gradient's storage (False: private copy)
 FUSE_BN_REDUCE = True    # pooling / head backward also accumulate the producing block's BN2 backward reductions
 # a block followed by the output head hands it the pre-activation: BN+ReLU happen inside the head kernels
 HEAD_ON_Z = os.environ.get("SEGK_HEAD_ON_Z", "1") != "0"       # the env switch is for same-box A/B runs of bench.py
@@ -314,17 +326,27 @@ class KernelTimer:
 
     def __init__(self):
         self.rows = {}
+        self.levels = {}      # (level name, phase) -> the same record, for spans opened inside a named DoubleConv node
 
     def span(self, tag, flops=0.0, nbytes=0.0):
         return _Span(self, tag, flops, nbytes)
 
+    @staticmethod
+    def _sum(rows):
+        out = {}
+        for key, r in rows.items():
+            ms = sum(a.elapsed_time(b) for a, b in r["ev"])
+            out[key] = {"launches": len(r["ev"]), "ms": ms, "flops": r["flops"], "bytes": r["bytes"]}
+        return out
+
     def summary(self):
         torch.cuda.synchronize()
-        out = {}
-        for tag, r in self.rows.items():
-            ms = sum(a.elapsed_time(b) for a, b in r["ev"])
-            out[tag] = {"launches": len(r["ev"]), "ms": ms, "flops": r["flops"], "bytes": r["bytes"]}
-        return out
+        return self._sum(self.rows)
+
+    def level_summary(self):
+        """{(level, phase): record}; phase = fwd | dgrad | wgrad (the 3x3 conv kernels of the block) | other."""
+        torch.cuda.synchronize()
+        return self._sum(self.levels)
 
 
 class _Span:
@@ -342,6 +364,12 @@ class _Span:
         r["ev"].append((self.a, b))
         r["flops"] += self.flops
         r["bytes"] += self.nbytes
+        if _LEVEL is not None:
+            phase = {"conv3x3_igemm": "dgrad" if _LEVEL[1] else "fwd", "wgrad3x3": "wgrad"}.get(self.tag, "other")
+            r = self.t.levels.setdefault((_LEVEL[0], phase), {"ev": [], "flops": 0.0, "bytes": 0.0})
+            r["ev"].append((self.a, b))
+            r["flops"] += self.flops
+            r["bytes"] += self.nbytes
 
 
 class _NoSpan:
@@ -354,6 +382,48 @@ class _NoSpan:
 
 _NOSPAN = _NoSpan()
 TIMER = None          # set to a KernelTimer() to collect per-kernel timings
+_LEVEL = None         # (level name, in backward) while a named DoubleConv node runs with a TIMER installed
+
+
+def name_levels(model):
+    """Give every DoubleConv block of `model` its module path as level name (bench.py: per-level roofline report)."""
+    for name, m in model.named_modules():
+        if hasattr(m, "bn_modules") and hasattr(m, "cache"):
+            m.__dict__["_segk_level"] = name or "block"
+
+
+class _level_scope:
+    def __init__(self, mod, backward):
+        self.v = (mod.__dict__.get("_segk_level"), backward) if TIMER is not None else None
+
+    def __enter__(self):
+        global _LEVEL
+        self.prev = _LEVEL
+        if self.v is not None and self.v[0] is not None:
+            _LEVEL = self.v
+
+    def __exit__(self, *exc):
+        global _LEVEL
+        _LEVEL = self.prev
+        return False
+
+
+def clock_probe(launches=4, blocks=256, iters=20000, device=None):
+    """Median shader clock (GHz) the chip holds under a dense bf16 MFMA probe (segk_clock_probe: `launches` back-to-back
+    launches of `iters` x 16 MFMAs per wave, the last one evaluated).  Diagnostic only: a number that explains box-to-box
+    spread of the MFMA-bound kernels; it synchronises the device."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.zeros((blocks * 4 * 2,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        for _ in range(launches):
+            _lib.call("segk_clock_probe", out.data_ptr(), blocks, iters, _stream())
+        torch.cuda.synchronize(dev)
+    t = out.view(-1, 2).double().cpu()
+    ghz = (t[:, 0] / t[:, 1].clamp(min=1.0)) * 0.1
+    return {"median_ghz": round(float(ghz.median()), 4), "min_ghz": round(float(ghz.min()), 4),
+            "max_ghz": round(float(ghz.max()), 4), "probe_ms": round(float(t[:, 1].median()) / 1e5, 3),
+            "method": f"s_memtime / s_memrealtime (100 MHz) around {iters} x 16 v_mfma_f32_32x32x16_bf16 per wave, one wave "
+                      f"per SIMD on {blocks} workgroups, launch {launches} of {launches} back to back"}
 
 
 def _span(tag, flops=0.0, nbytes=0.0):
@@ -451,9 +521,10 @@ def bn_finalize(stats, tiles, C, count, conv_bias, bn_w, bn_b, rmean, rvar, mome
     Cp = pad32(C)
     scale, shift = _f32(Cp, dev), _f32(Cp, dev)
     mean, rstd = _f32(Cp, dev), _f32(Cp, dev)
-    _lib.call("segk_bn_finalize", _p(stats), tiles, Cp, C, float(count), _p(conv_bias), bn_w.data_ptr(),
-              bn_b.data_ptr(), _p(rmean), _p(rvar), float(momentum), float(eps), int(training), scale.data_ptr(),
-              shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream())
+    with _span("bn_finalize", 0.0, 8.0 * tiles * Cp if training else 0.0):
+        _lib.call("segk_bn_finalize", _p(stats), tiles, Cp, C, float(count), _p(conv_bias), bn_w.data_ptr(),
+                  bn_b.data_ptr(), _p(rmean), _p(rvar), float(momentum), float(eps), int(training), scale.data_ptr(),
+                  shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream())
     return scale, shift, mean, rstd
 
 
@@ -701,6 +772,11 @@ class DoubleConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, xa, xb, w1, b1, g1, be1, w2, b2, g2, be2, up_x, up_w, up_b, head_w, head_b):
+        with _level_scope(cfg.mod, False):
+            return DoubleConvFn._forward(ctx, cfg, xa, xb, w1, b1, g1, be1, w2, b2, g2, be2, up_x, up_w, up_b, head_w, head_b)
+
+    @staticmethod
+    def _forward(ctx, cfg, xa, xb, w1, b1, g1, be1, w2, b2, g2, be2, up_x, up_w, up_b, head_w, head_b):
         mod = cfg.mod
         dtype = mod.compute_dtype or _compute_dtype
         _require_cuda(xa, "DoubleConvReLU")
@@ -823,11 +899,18 @@ class DoubleConvFn(torch.autograd.Function):
         if logits is not None:
             return logits
         if pooled is not None:
-            return act_view(y, Cout), act_view(pooled, Cout)
+            y_out = act_view(y, Cout)
+            ctx.y_ref = weakref.ref(y_out)     # backward asks it whether the caller hooked the skip tensor (see there)
+            return y_out, act_view(pooled, Cout)
         return act_view(y, Cout)
 
     @staticmethod
     def backward(ctx, *grads):
+        with _level_scope(ctx.cfg.mod, True):
+            return DoubleConvFn._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, *grads):
         frozen = not ctx.training      # eval mode: both BatchNorms are fixed affine maps (running statistics)
         (xa_t, xb_t, z1, z2, sc1, sh1, mu1, rs1, sc2, sh2, mu2, rs2, w1, w2, a1, y, up_t, up_w, head_w) = ctx.saved_tensors
         cfg, dtype = ctx.cfg, ctx.dtype
@@ -862,8 +945,15 @@ class DoubleConvFn(torch.autograd.Function):
                 else:
                     # the skip gradient arrives as an act tensor (fresh output of the consumer's data-gradient kernel;
                     # converted copy otherwise): the pooled gradient is routed INTO its storage, one kernel instead of
-                    # a pooling backward plus a full-resolution add
+                    # a pooling backward plus a full-resolution add.  A backward must not change a gradient somebody
+                    # else can still see: with a tensor hook on the skip tensor (register_hook: the hook may keep the
+                    # tensor it is handed; retain_grad() clones and is safe) the sum goes to a private copy instead.
+                    yo = getattr(ctx, "y_ref", lambda: None)()
+                    hooked = INPLACE_SKIP_GRAD is False or (yo is not None and bool(yo._backward_hooks))
                     keep, pdy, _ = _raw(dy, dtype)
+                    if hooked and keep.data_ptr() == dy.data_ptr():      # zero-copy act tensor: the caller's own storage
+                        keep = _private_act_copy(keep, dtype)
+                        pdy = keep.data_ptr()
                     acc, nbytes = 1, 3.25
                 nb = _lib.query("segk_maxpool_bwd_stat_blocks", B, H, W, Coutp, _DT[dtype]) if FUSE_BN_REDUCE else 0
                 with _span("maxpool_bwd", 0.0, nbytes * P * Cout * _es(dtype)):

@@ -63,6 +63,10 @@ class GradSync:
         self._pending = {}           # bucket index -> work handle (or None)
         self._stream = None
         self._hooks = []
+        self._next = 0               # buckets [0, _next) have been launched in this window (launches are strictly in order)
+        self.timing = False          # True: record HIP events per bucket launch / completion (bench.py, rank 0)
+        self._t0 = self._t1 = None
+        self._trace = []
         self.collectives = 0         # all-reduces issued so far (tests: un-armed micro-steps must not communicate)
         self.direct_grads = 0        # gradients found already in their bucket slice when their bucket was launched
         if self.world > 1:
@@ -86,6 +90,9 @@ class GradSync:
     def arm(self):
         """Call before the backward of the micro-batch that ends an accumulation window."""
         self._armed = True
+        self._next = 0
+        self._t0 = self._t1 = None
+        self._trace = []
         self._count = [0] * len(self.buckets)
         self._need = [sum(1 for p in b if p.requires_grad) for b in self.buckets]   # parameters frozen since __init__
         if self.world > 1:
@@ -107,8 +114,39 @@ class GradSync:
             return
         bi = self._slot[p][0]
         self._count[bi] += 1
-        if self.overlap and self._count[bi] == self._need[bi]:
-            self._launch(bi)
+        if not self.overlap:
+            return
+        # Collectives are matched across ranks by ISSUE ORDER, so buckets are launched strictly in index order: bucket k
+        # goes out only once buckets 0..k-1 have gone (a parameter that receives no gradient on one rank only -- a
+        # data-dependent branch, an unused head -- would otherwise make that rank issue its all-reduces in another order
+        # than its peers: a hang, or silently mixed buckets).  A bucket whose count never fills waits for sync(), which
+        # launches the rest in the same index order on every rank.
+        while self._next < len(self.buckets) and self._count[self._next] == self._need[self._next]:
+            self._launch(self._next)
+            self._next += 1
+
+    # -- optional event trace of the overlap (bench.py: per-bucket launch times relative to the start of backward) -------
+    def backward_begin(self):
+        if self.timing and self._flat and self._flat[0].is_cuda:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record()
+
+    def backward_end(self):
+        if self.timing and self._t0 is not None:
+            self._t1 = torch.cuda.Event(enable_timing=True)
+            self._t1.record()
+
+    def overlap_trace(self):
+        """After sync() + a device synchronisation: per bucket, when its all-reduce was enqueued behind the backward
+        kernels (compute stream) and when it had finished (side stream), in ms from backward_begin()."""
+        if self._t0 is None:
+            return None
+        out = {"backward_ms": round(self._t0.elapsed_time(self._t1), 3) if self._t1 is not None else None, "buckets": []}
+        for bi, nbytes, ev_l, ev_d in self._trace:
+            out["buckets"].append({"bucket": bi, "mbytes": round(nbytes / 1e6, 2),
+                                   "launched_at_ms": round(self._t0.elapsed_time(ev_l), 3),
+                                   "done_at_ms": round(self._t0.elapsed_time(ev_d), 3)})
+        return out
 
     def _launch(self, bi):
         flat = self._flat[bi]
@@ -122,6 +160,10 @@ class GradSync:
             else:
                 self.direct_grads += 1
         side = flat.is_cuda and self.overlap
+        ev_l = ev_d = None
+        if self.timing and self._t0 is not None and flat.is_cuda:
+            ev_l = torch.cuda.Event(enable_timing=True)
+            ev_l.record()                                 # compute stream: every gradient of the bucket exists here
         if side:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)
@@ -138,6 +180,12 @@ class GradSync:
             avg = self.backend == "nccl"                  # RCCL averages in the collective; gloo has no AVG
             work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group,
                                    async_op=True)
+            if ev_l is not None:
+                if not side:
+                    work.wait()
+                ev_d = torch.cuda.Event(enable_timing=True)
+                ev_d.record()                             # the stream the collective was enqueued on
+                self._trace.append((bi, flat.numel() * flat.element_size(), ev_l, ev_d))
         self.collectives += 1
         for p, v in zip([q for q in self.buckets[bi] if q.grad is not None and not self._in_place(q)], move_dst):
             p.grad = v                                    # .grad now lives in the bucket
@@ -149,9 +197,10 @@ class GradSync:
         if self.world == 1:
             self._armed = False
             return
-        for bi in range(len(self.buckets)):
+        for bi in range(self._next if self._armed else 0, len(self.buckets)):   # the rest, in index order on every rank
             if bi not in self._pending:
                 self._launch(bi)
+        self._next = 0
         for bi, (work, avg) in sorted(self._pending.items()):
             work.wait()                                   # makes the current stream wait for the collective
         if self._stream is not None:

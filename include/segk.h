@@ -30,7 +30,12 @@ extern "C" {
 
 typedef void* segk_stream_t; /* hipStream_t */
 
+/* ABI version and the number of entry points this header declares: segk_version() / segk_entry_count() of a library
+ * must equal them (image_segmentation_amd/_lib.py refuses a library whose values differ from the table it binds) */
+#define SEGK_ABI_VERSION 300
+#define SEGK_ENTRY_COUNT 67
 int segk_version(void);
+int segk_entry_count(void);
 /* first 16 hex digits of the sha256 over the sources this library was built from (image_segmentation_amd/build.py:
  * source_hash) -- lets a host check that a shipped libsegk.so matches the sources beside it */
 const char* segk_build_id(void);
@@ -286,6 +291,13 @@ int segk_prob_loss_fwd(const float* probs, const int64_t* labels, const float* c
 int segk_prob_loss_bwd(const float* probs, const int64_t* labels, const float* class_weights, const float* state,
                        const float* grad_out, int N, int C, long HW, int ignore_index, float dice_weight,
                        float nll_weight, int nll_log, float eps, float* dprobs, segk_stream_t s);
+
+/* ---- diagnostics (not on the product path) ---------------------------------------------------------
+ * The shader clock held under a dense bf16 MFMA load: `blocks` workgroups of four waves (one per SIMD) run `iters` rounds of
+ * 16 v_mfma_f32_32x32x16_bf16 each and write, per wave w, out[2w] = elapsed shader cycles (s_memtime) and out[2w+1] =
+ * elapsed ticks of the constant 100 MHz counter (s_memrealtime): clock = out[2w] / out[2w+1] x 100 MHz.  bench.py puts
+ * the median into its line so that box-to-box spread is explained by a number. */
+int segk_clock_probe(uint64_t* out, int blocks, int iters, segk_stream_t s);
 
 /* ---- metric: argmax + confusion matrix (utils/MetricsHistory.py:65-75) ---------------------------
  * M[pred*8 + label] += count (uint64, caller zeroes); TP/FP/FN/TN follow on the host. */

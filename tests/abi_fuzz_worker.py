@@ -14,7 +14,7 @@ from image_segmentation_amd import _lib          # noqa: E402  (signature table 
 
 lib = C.CDLL(sys.argv[1])
 lib.segk_last_error.restype = C.c_char_p
-QUERIES = {"segk_version", "segk_stem3x3_wgrad_slabs", "segk_stem3x3_rows", "segk_pack_convt_chunk", "segk_conv_tiles", "segk_bn_stats_floats", "segk_conv_writes_act_q", "segk_wgrad_tiles", "segk_wgrad_split",
+QUERIES = {"segk_version", "segk_entry_count", "segk_stem3x3_wgrad_slabs", "segk_stem3x3_rows", "segk_pack_convt_chunk", "segk_conv_tiles", "segk_bn_stats_floats", "segk_conv_writes_act_q", "segk_wgrad_tiles", "segk_wgrad_split",
            "segk_bn_bwd_blocks", "segk_maxpool_bwd_stat_blocks", "segk_head_part_floats", "segk_head_bwd_blocks",
            "segk_loss_part_floats", "segk_loss_state_floats"}
 

@@ -41,7 +41,9 @@ def run(rank, world, port, dtype_name, out_path, B=2, S=64):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))   # a peer that
+    # died before the rendezvous must not leave this rank waiting forever
     res = {"rank": rank, "dtype": dtype_name, "ok": False}
     try:
         import image_segmentation_amd as seg

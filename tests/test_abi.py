@@ -49,9 +49,33 @@ def test_ctypes_table_matches_header(lib):
         assert len(lib.SIGNATURES[name][1]) == nargs, name
 
 
+def test_header_macros_match_declarations_and_binding(lib):
+    """SEGK_ENTRY_COUNT / SEGK_ABI_VERSION are what _lib.load() compares a library against: they must follow the header's
+    own declarations and the ctypes table."""
+    txt = open(os.path.join(ROOT, "include", "segk.h")).read()
+    count = int(re.search(r"#define\s+SEGK_ENTRY_COUNT\s+(\d+)", txt).group(1))
+    version = int(re.search(r"#define\s+SEGK_ABI_VERSION\s+(\d+)", txt).group(1))
+    assert count == len(header_protos()) == len(lib.SIGNATURES)
+    assert version == lib.ABI_VERSION
+
+
+def test_load_refuses_a_library_with_another_abi(lib, monkeypatch):
+    """A diagnostic build made from another header (SEGK_LIB / kbench --lib) is refused instead of being driven with this
+    binding's buffer-size queries (the round-2 GPU fault: DESIGN.md 4.2)."""
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "ABI_VERSION", lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="refusing to drive"):
+        lib.load()
+    monkeypatch.setattr(lib, "ABI_VERSION", lib.ABI_VERSION - 1)
+    sig = dict(lib.SIGNATURES); sig.pop("segk_clock_probe")
+    monkeypatch.setattr(lib, "SIGNATURES", sig)
+    with pytest.raises(RuntimeError, match="refusing to drive"):
+        lib.load()
+
+
 def test_load_and_version(lib):
     so = lib.load()
-    assert so.segk_version() >= 200
+    assert so.segk_version() == lib.ABI_VERSION and so.segk_entry_count() == len(lib.SIGNATURES)
     assert so.segk_last_error() is not None
     # pure size queries work without a GPU
     assert lib.query("segk_conv_tiles", 2, 32, 32, 256, 64, 1) == 2 * 2 * 1    # 16x32 tiles: bf16 64-ch output, long K

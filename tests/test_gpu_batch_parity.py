@@ -1,0 +1,162 @@
+"""GPU (-m gpu): parity AT THE BATCH the bench numbers are taken on (BASELINE configs 2, 4 and 5), forward + loss only
+so that the CPU oracle stays within seconds:
+
+  config 2  U-Net 3-class, B=32, 3x256x256, CrossEntropy       (reference unet/unet.py:93-105, utils/training.py:47)
+  config 5  U-Net 3-class, B=8, 3x512x512, weighted Dice + CE   (utils/weighted_loss.py:140-166)
+  config 4  CLIP-UNet decoder + head, B=16, 224x224, fed the ORACLE's encoder features (clip/clipunet.py:139-144,184-188)
+
+These geometries reach what the B=1 / B=2 / B=4 tests cannot: persistent-unit ranges per XCD over thousands of units,
+BatchNorm partial rows beyond 1024 inside a model, 32-bit offsets into 537 MB tensors.
+fp32 mode: logits within 1e-3 of the oracle and argmax masks bit-exact (the north-star gate); bf16 mode: the gates of
+tests/test_gpu_fullsize.py.  Plus a bf16 GRADIENT test at a conditioned batch (B=8, 128x128), where batch statistics rest
+on >= 512 values per channel at every level and the per-tensor gates can be tight."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.fill import fill, labels, fill_module
+from oracle import unet_ref, losses_ref, clipunet_ref, clip_vit_ref
+
+pytestmark = pytest.mark.gpu
+CW3 = [0.2046795970925636, 1.0271954434416883, 1.2293222812780409]
+
+
+@pytest.fixture(scope="module")
+def seg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import image_segmentation_amd as s
+    yield s
+    s.set_compute_dtype(torch.bfloat16)
+
+
+_ORACLE = {}
+
+
+def unet_oracle(B, S, loss_name):
+    """CPU oracle: training-mode forward (batch statistics) + loss, no backward (cached for both compute modes)."""
+    key = (B, S, loss_name)
+    if key not in _ORACLE:
+        ref = unet_ref.unet(3, 3); fill_module(ref, 1000); ref.train()
+        X = fill((B, 3, S, S), 1, 0, 1); Y = labels((B, S, S), 2, 3)
+        with torch.no_grad():
+            lr = ref(X)
+            if loss_name == "ce":
+                loss = losses_ref.cross_entropy(lr, Y)
+            else:
+                loss = losses_ref.dice_ce(lr, Y, class_weights=torch.tensor(CW3), smooth_dice=1.0)
+        _ORACLE[key] = (X, Y, lr, float(loss))
+    return _ORACLE[key]
+
+
+def unet_hip(seg, dtype, B, S, loss_name):
+    X, Y, _, _ = unet_oracle(B, S, loss_name)
+    seg.set_compute_dtype(dtype)
+    m = seg.unet(3, 3); fill_module(m, 1000); m.cuda().train()
+    # autograd stays ON (no backward is run): the training forward then takes exactly the kernels of the bench step
+    # (both weight layouts, the hidden-activation side output of the second conv of every block)
+    lg = m(X.cuda())
+    if loss_name == "ce":
+        loss = seg.CrossEntropyLoss()(lg, Y.cuda())
+    else:
+        loss = seg.WeightedDiceCELoss(smooth_dice=1.0, class_weights=torch.tensor(CW3))(lg, Y.cuda())
+    torch.cuda.synchronize()
+    return lg.detach().float().cpu(), float(loss)
+
+
+def check_fp32(lg, loss, lr, loss_ref):
+    assert (lg - lr).abs().max().item() < 1e-3                 # north-star gate: logits within 1e-3
+    assert torch.equal(lg.argmax(1), lr.argmax(1))             # argmax masks bit-exact
+    assert abs(loss - loss_ref) < 2e-5
+
+
+def check_bf16(lg, loss, lr, loss_ref):
+    d = (lg - lr).abs()
+    assert d.max().item() < 0.2 and d.mean().item() < 0.02, (d.max().item(), d.mean().item())
+    assert (lg.argmax(1) == lr.argmax(1)).float().mean().item() > 0.975
+    assert abs(loss - loss_ref) < 2e-2
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("cfg", [(32, 256, "ce"), (8, 512, "dicece")], ids=["config2_B32_256", "config5_B8_512_dicece"])
+def test_unet_forward_at_bench_batch_fp32(seg, cfg):
+    B, S, loss_name = cfg
+    _, _, lr, loss_ref = unet_oracle(B, S, loss_name)
+    lg, loss = unet_hip(seg, torch.float32, B, S, loss_name)
+    check_fp32(lg, loss, lr, loss_ref)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("cfg", [(32, 256, "ce"), (8, 512, "dicece")], ids=["config2_B32_256", "config5_B8_512_dicece"])
+def test_unet_forward_at_bench_batch_bf16(seg, cfg):
+    B, S, loss_name = cfg
+    _, _, lr, loss_ref = unet_oracle(B, S, loss_name)
+    lg, loss = unet_hip(seg, torch.bfloat16, B, S, loss_name)
+    check_bf16(lg, loss, lr, loss_ref)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_clip_decoder_at_config4_batch(seg, dtype):
+    """Config 4 (B=16, 224x224): the decoder + head on the HIP kernels against the oracle decoder, both fed the ORACLE's
+    ViT-B/16 features (local random-weight config, portable-fill weights: oracle/clip_vit_ref.py)."""
+    pytest.importorskip("transformers")
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    B = 16
+    vit = CLIPVisionModel(CLIPVisionConfig(patch_size=16)); fill_module(vit, 8100); vit.eval()
+    X = fill((B, 3, 224, 224), 9, -1, 1)
+    bott, skips = clip_vit_ref.encoder_features(vit, X, [3, 5, 7, 9])
+    ref = clipunet_ref.UNetDecoder(768, [1024, 512, 256, 128, 64]); fill_module(ref, 5000); ref.train()
+    rh = torch.nn.Conv2d(64, 4, 1); fill_module(rh, 6000)
+    Y = labels((B, 224, 224), 3, 4)
+    with torch.no_grad():
+        lr = rh(ref(bott, skips))
+        loss_ref = float(losses_ref.cross_entropy(lr, Y))
+    seg.set_compute_dtype(dtype)
+    from image_segmentation_amd import ops
+    dec = seg.UNetDecoder(768, [1024, 512, 256, 128, 64]); fill_module(dec, 5000)
+    head = torch.nn.Conv2d(64, 4, 1); fill_module(head, 6000)
+    dec.cuda().train(); head.cuda()
+    d = dec(bott.cuda(), [s.cuda() for s in skips])               # autograd on: the training-forward kernels
+    lg = ops.HeadFn.apply(dec, d, head.weight, head.bias)
+    loss = float(seg.CrossEntropyLoss()(lg, Y.cuda()))
+    lg = lg.detach().float().cpu()
+    if dtype == torch.float32:
+        assert (lg - lr).abs().max().item() < 2e-3                  # four decoder blocks deep on O(1) features
+        same = lg.argmax(1) == lr.argmax(1)
+        top2 = lr.topk(2, dim=1).values
+        assert bool((same | ((top2[:, 0] - top2[:, 1]) < 1e-4)).all())    # disagreements only inside reference near-ties
+        assert abs(loss - loss_ref) < 1e-4
+    else:
+        check_bf16(lg, loss, lr, loss_ref)
+
+
+@pytest.mark.timeout(900)
+def test_unet_bf16_gradients_at_a_conditioned_batch(seg):
+    """B=8, 3x128x128, CrossEntropy: every BatchNorm of the U-Net sees >= 512 values per channel (down5: 8 x 8 x 8), so
+    bf16 gradients can be held to tight per-tensor gates against the fp32 oracle: weights cosine >= 0.99 and norm
+    within 3 %, BatchNorm vectors / ConvT + head biases cosine >= 0.99 and norm within 8 %.  A 5 % scale error in a
+    BatchNorm-vector gradient fails here (it passed the B=1 gates of test_gpu_fullsize.py)."""
+    B, S = 8, 128
+    ref = unet_ref.unet(3, 3); fill_module(ref, 1000); ref.train()
+    X = fill((B, 3, S, S), 1, 0, 1); Y = labels((B, S, S), 2, 3)
+    losses_ref.cross_entropy(ref(X), Y).backward()
+    gref = {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
+    seg.set_compute_dtype(torch.bfloat16)
+    m = seg.unet(3, 3); fill_module(m, 1000); m.cuda().train()
+    seg.CrossEntropyLoss()(m(X.cuda()), Y.cuda()).backward()
+    torch.cuda.synchronize()
+    g = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    stats = {}
+    for n, r in gref.items():
+        if n.endswith(".bias") and ("doubleConvReLU.0" in n or "doubleConvReLU.3" in n):
+            assert g[n].abs().max().item() == 0.0, n               # cancels in the batch-statistics BatchNorm
+            continue
+        a, b = g[n].double().flatten(), r.double().flatten()
+        stats[n] = (float(a @ b / (a.norm() * b.norm() + 1e-30)), float(a.norm() / (b.norm() + 1e-30)), r.dim())
+    worst = sorted(stats.items(), key=lambda kv: kv[1][0])[:6]
+    wr = sorted(stats.items(), key=lambda kv: -abs(kv[1][1] - 1.0))[:6]
+    print("bf16 B=8 128x128: lowest cosines", worst, "largest norm deviations", wr)
+    for n, (cos, ratio, dim) in stats.items():
+        assert cos >= 0.99, (n, cos, worst)
+        assert abs(ratio - 1.0) <= (0.03 if dim > 1 else 0.08), (n, ratio, wr)

@@ -5,6 +5,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -18,7 +19,27 @@ def run_check(dtype, out_prefix):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), "2", str(port), dtype,
                                out_prefix], env=env) for r in range(2)]
-    rcs = [p.wait(timeout=600) for p in procs]
+    rcs, hung = [None, None], []
+    try:
+        deadline = time.monotonic() + 600
+        for r, p in enumerate(procs):
+            try:
+                rcs[r] = p.wait(timeout=max(1.0, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                hung.append(r)
+    finally:
+        # a rank that crashed before the rendezvous leaves its peer blocked in init_process_group or a collective: no child
+        # may outlive this call holding cuda:0 (exact PIDs only -- these are the two processes started above)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+    if hung:
+        raise AssertionError(f"rank(s) {hung} did not finish within 600 s and were killed; exit codes {rcs}")
     res = [json.load(open(f"{out_prefix}.rank{r}.json")) for r in range(2)]
     return rcs, res
 

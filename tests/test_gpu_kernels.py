@@ -573,3 +573,33 @@ def test_stem_weight_gradient_from_nchw_input(ops, case):
     _lib.call("segk_wgrad_reduce", slabs.data_ptr(), S, grad.data_ptr(), 64, 9 * Cin, 0, 64, 32, 0, 1, s)
     assert (back(grad) - w.grad).abs().max() <= 1e-4 * np.sqrt(B * H * W), case
     assert torch.isfinite(slabs).all()
+
+
+def test_biased_conv_on_rs_shape_falls_through_to_ws_and_refuses_statistics(ops):
+    """The round-2 GPU memory fault: on the shapes the register-stationary kernel serves (bf16, Cin 32/64,
+    N % 64 == 0, W > 16) a BIASED conv falls through to the weight-stationary kernel, whose BatchNorm partial rows are per
+    tile while segk_conv_tiles() sizes the statistics buffer for conv_rs's per-wave rows.  (i) the fall-through itself
+    (bias, no statistics: reference autoencoder/autoencoder.py:188-191 is such a layer) computes conv + bias;
+    (ii) bias together with statistics is refused with -2 instead of overrunning the buffer."""
+    from image_segmentation_amd import _lib
+    dtype = torch.bfloat16
+    B, C, H, W = 2, 64, 24, 48
+    x = fill((B, C, H, W), 1, -1, 1); w = fill((C, C, 3, 3), 2, -1, 1) / 24; b = fill((C,), 3, -1, 1)
+    per_tile_rows = B * ((H + 7) // 8) * ((W + 31) // 32)                         # what the weight-stationary kernel would write
+    assert _lib.query("segk_conv_tiles", B, H, W, C, C, 1) % 32 == 0 and per_tile_rows == 12   # sized for conv_rs (8 x GW x 4 rows)
+    xa = ops.to_act(dev(x), dtype); pa, Cp = ops.act_info(xa, dtype)
+    wp = ops.pack_conv(dev(w), C, 0, dtype, 0)
+    bp = dev(b)
+    out = torch.empty((B, H, W, Cp), dtype=dtype, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.call("segk_conv3x3", pa, 0, wp.data_ptr(), bp.data_ptr(), 0, 0, out.data_ptr(), 0, 0, B, H, W, Cp, 0, Cp, 0, 1, s)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), b, padding=1)
+    assert (back(ops.act_view(out, C)) - ref).abs().max().item() < tol(dtype, 1) * 1.5
+    tiles = _lib.query("segk_conv_tiles", B, H, W, Cp, Cp, 1)
+    st = torch.zeros((_lib.query("segk_bn_stats_floats", tiles, Cp),), dtype=torch.float32, device="cuda")
+    rc = _lib.load().segk_conv3x3(pa, 0, wp.data_ptr(), bp.data_ptr(), 0, 0, out.data_ptr(), 0, st.data_ptr(), B, H, W,
+                                  Cp, 0, Cp, 0, 1, s)
+    assert rc == -2 and b"bias together with BatchNorm statistics" in _lib.load().segk_last_error()
+    torch.cuda.synchronize()
+    assert float(st.abs().sum()) == 0.0                                           # nothing was launched

@@ -461,3 +461,42 @@ def test_eval_mode_backward_matches_oracle(seg):
             assert torch.equal(a.cpu(), b), n
     finally:
         seg.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_skip_gradient_seen_by_a_tensor_hook_is_not_modified_in_place(seg, dtype):
+    """The pooling backward normally adds the routed pool gradient INTO the storage of the incoming skip gradient (one
+    kernel instead of pooling backward + a full-resolution add).  A hook registered on the skip tensor may keep the
+    gradient it is handed: that tensor must still hold the skip gradient alone after backward (torch's contract: a
+    backward does not modify its grad inputs), and the parameter gradients must equal those of the un-hooked run."""
+    seg.set_compute_dtype(dtype)
+    x = fill((2, 3, 32, 64), 1, 0, 1).cuda()
+    results = []
+    for hook in (False, True):
+        dc = seg.DoubleConvReLU(3, 64); down = seg.Down(64, 128); up = seg.Up(128, 64)
+        fill_module(dc, 1000); fill_module(down, 2000); fill_module(up, 3000)
+        dc.cuda().train(); down.cuda().train(); up.cuda().train()
+        y, pooled = dc(x, emit_pool=True)
+        seen = []
+        if hook:
+            y.register_hook(lambda g: seen.append(g))
+        out = up(y, down(y, pooled=pooled))                      # y is used twice: skip connection and (pooled) main path
+        (out.float() * fill(tuple(out.shape), 7, -1, 1).cuda()).sum().backward()
+        torch.cuda.synchronize()
+        results.append(({n: q.grad.float().clone() for n, q in dc.named_parameters()},
+                        None if not seen else seen[0].detach().float().clone()))
+    (g0, _), (g1, skip_grad) = results
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n                      # same kernels, same order: bit-identical
+    # the hooked tensor is the gradient of the skip connection alone: it equals the un-pooled part, i.e. what Up's
+    # backward produced -- recompute it by running the same graph with the pooled path cut off
+    dc = seg.DoubleConvReLU(3, 64); down = seg.Down(64, 128); up = seg.Up(128, 64)
+    fill_module(dc, 1000); fill_module(down, 2000); fill_module(up, 3000)
+    dc.cuda().train(); down.cuda().train(); up.cuda().train()
+    y, pooled = dc(x, emit_pool=True)
+    yd = y.detach().requires_grad_(True)
+    out = up(yd, down(y, pooled=pooled).detach())
+    (out.float() * fill(tuple(out.shape), 7, -1, 1).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(skip_grad, yd.grad.float())
+    seg.set_compute_dtype(torch.bfloat16)

@@ -197,3 +197,48 @@ def test_resize_geometry_and_host_path_match_oracle():
     back = process_batch_reverse(logits, meta)
     for b, l, m in zip(back, logits, meta):
         assert torch.equal(b, resize_ref.reverse_resize_and_padding(l, m))
+
+
+def test_clip_encoder_loads_both_transformers_key_layouts():
+    """Reference CLIP-UNet checkpoints were written with transformers 4.x, whose CLIPVisionModel nests the transformer
+    under `.vision_model` (keys encoder.clip_vit.vision_model.*; reference clip/clipunet.py:25-26,
+    prompt_based/segmentation_webapp/app.py:65-79); 5.x has no such level.  ClipViTEncoder maps the keys to whichever
+    layout the installed module has -- checked in both directions with synthetic state dicts, strict loading, through
+    the ClipUNet parent (prefix `encoder.`)."""
+    pytest.importorskip("transformers")
+    from transformers import CLIPVisionConfig
+    cfg = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                           image_size=32, patch_size=16)
+    src = seg.ClipUNet(num_classes=4, decoder_channels=[64, 32], encoder=seg.ClipViTEncoder.from_config(cfg, skip_indices=[1]))
+    fill_module(src, 4000)
+    sd = src.state_dict()
+    own = "encoder.clip_vit."
+    nested_here = hasattr(src.encoder.clip_vit, "vision_model")
+    flat = {(own + k[len(own) + len("vision_model."):] if k.startswith(own + "vision_model.") else k): v for k, v in sd.items()}
+    nested = {(own + "vision_model." + k[len(own):] if k.startswith(own) else k): v for k, v in flat.items()}
+    assert any(k.startswith(own + "vision_model.") for k in nested) and not any("vision_model" in k for k in flat)
+    for name, ckpt in (("4.x layout", nested), ("5.x layout", flat)):
+        dst = seg.ClipUNet(num_classes=4, decoder_channels=[64, 32], encoder=seg.ClipViTEncoder.from_config(cfg, skip_indices=[1]))
+        res = dst.load_state_dict(dict(ckpt), strict=True)
+        assert not res.missing_keys and not res.unexpected_keys, name
+        for k, v in dst.state_dict().items():
+            assert torch.equal(v, sd[k]), (name, k)
+    # the opposite module layout (a transformer nested under `.vision_model`, as transformers 4.x builds it)
+    if not nested_here:
+        class Nested(torch.nn.Module):
+            def __init__(self, inner):
+                super().__init__()
+                self.vision_model, self.config = inner, inner.config
+        dst = seg.ClipUNet(num_classes=4, decoder_channels=[64, 32], encoder=seg.ClipViTEncoder.from_config(cfg, skip_indices=[1]))
+        dst.encoder.clip_vit = Nested(dst.encoder.clip_vit)
+        for name, ckpt in (("4.x layout", nested), ("5.x layout", flat)):
+            res = dst.load_state_dict(dict(ckpt), strict=True)
+            assert not res.missing_keys and not res.unexpected_keys, name
+        got = dst.state_dict()
+        assert all(torch.equal(got[k], v) for k, v in nested.items()) and set(got) == set(nested)
+    # a persistent position_ids buffer of an old release is dropped instead of failing the strict load
+    old = dict(nested)
+    old[own + "vision_model.embeddings.position_ids"] = torch.arange(5).unsqueeze(0)
+    dst = seg.ClipUNet(num_classes=4, decoder_channels=[64, 32], encoder=seg.ClipViTEncoder.from_config(cfg, skip_indices=[1]))
+    if own[:-1] + ".embeddings.position_ids" not in dst.state_dict() and own + "embeddings.position_ids" not in dst.state_dict():
+        dst.load_state_dict(old, strict=True)

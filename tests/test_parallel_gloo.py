@@ -50,6 +50,34 @@ def _worker(rank, world, port, q):
         for a, b in zip(res["armed"], res["flush"]):
             assert torch.equal(a, b)
         assert gs.collectives == 3 * len(gs.buckets)
+        # a parameter that receives no gradient on ONE rank only (data-dependent branch): hook-launched buckets go out
+        # strictly in index order, so both ranks issue the same sequence of collectives (the middle layer's bucket and the
+        # ones after it wait for sync() on rank 1) -- no hang, no mixed buckets; the idle rank contributes zeros
+        gs.remove()
+        torch.manual_seed(1)
+        m2 = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+        gs2 = GradSync(m2, bucket_mb=0.0003)
+        assert len(gs2.buckets) >= 3
+
+        def fwd2(r):
+            h = m2[0](torch.full((5, 8), float(r + 1)))          # rank r's batch
+            if r == 0:
+                h = m2[1](h)
+            return m2[2](h).sum()
+        singles = []
+        for r in range(world):
+            m2.zero_grad()
+            fwd2(r).backward()
+            singles.append([None if p.grad is None else p.grad.clone() for p in m2.parameters()])
+        m2.zero_grad()
+        gs2.arm()
+        fwd2(rank).backward()
+        gs2.sync()
+        for i, p in enumerate(m2.parameters()):
+            w2 = sum(torch.zeros_like(p) if s_[i] is None else s_[i] for s_ in singles) / world
+            assert torch.allclose(p.grad, w2, atol=1e-6), ("uneven", i)
+        gs2.remove()
+        gs = GradSync(model, bucket_mb=0.0003)
         # replicas start identical: rank 1 perturbs its parameters, a new synchroniser restores rank 0's
         if rank == 1:
             with torch.no_grad():

@@ -19,16 +19,4 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM S
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o r -- python $R/tools/kbench.py "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed: $grp" >> $OUT/errors.txt
 done
-python - <<PY
-import csv, glob, collections
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob("$OUT/p*/r_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open("$OUT/summary.txt", "w") as o:
-    for k, v in agg.items():
-        o.write(k + "\n")
-        for c, vals in v.items():
-            o.write(f"    {c:44s} {sum(vals)/len(vals):16.1f}  (n={len(vals)})\n")
-print(open("$OUT/summary.txt").read()[:6000])
-PY
+python $R/tools/pmc_post.py summary $OUT
