@@ -155,7 +155,14 @@ def run_workload(args, world, rank, dev, want_levels=False):
 
 def family_table(prof, n, peak):
     """per-kernel-family ms per step, achieved TFLOP/s and algorithmic GB/s from the instrumented steps"""
-    kernels = family_table(prof, n, peak)
+    kernels = {}
+    for tag, r in prof.items():
+        ms = r["ms"] / n
+        kernels[tag] = {
+            "launches_per_step": r["launches"] // n, "ms_per_step": round(ms, 4),
+            "tflops": round(r["flops"] / n / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+            "alg_GBps": round(r["bytes"] / n / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+        }
     return kernels
 
 

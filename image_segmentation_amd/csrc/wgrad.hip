@@ -316,35 +316,61 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
   const char* const zeros = (const char*)a.zeros;
 
   const int lp = lane >> 2, lc = lane & 3;                // pixel-in-chunk / 16-byte piece of the lane
+  // ---- DMA issue.  Per tile every wave moves NI = ceil(NINSTR / NWV) one-KiB pieces.  Everything about a piece that does
+  // not depend on the tile is computed ONCE per kernel: the lane's byte offset from the tile's first pixel (poff) and five
+  // flag bits (which side of the 10 x 18 patch the lane's pixel lies on: top, bottom, left, right; bit 4 = a pixel of the
+  // patch region's unused tail).  Per tile the address of a piece is then scalar tile base + poff, and a lane reads the zero
+  // page instead when its flags meet the tile's "this side is outside the image" bits: ~8 vector instructions per piece
+  // where a general form (any tile may cross the image edge) spends ~40 on
+  // divisions, bounds tests and 64-bit multiplies, issued by all eight waves in front of every tile's MFMAs (the general
+  // form lives on in wgrad_kernel, which serves images that are not whole 8 x 16 tiles).
+  constexpr int NI = (NINSTR + NWV - 1) / NWV;
+  int poff[NI];
+  unsigned pflag[(NI + 5) / 6];
+#pragma unroll
+  for (int q = 0; q < (NI + 5) / 6; ++q) pflag[q] = 0u;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = min(wave + NWV * i, NINSTR - 1);         // wave-uniform
+    if (j < WU * 8) {
+      const int blk = j >> 3, r = j & 7;
+      poff[i] = ((r * W + lp) * UC + blk * 32 + lc * 8) * 2;
+    } else {
+      const int jj = j - WU * 8;
+      const int blk = jj / 12, ch = jj - blk * 12;
+      const int pp = ch * 16 + lp;
+      const int py = pp / 18, px = pp - py * 18;
+      poff[i] = (((py - 1) * W + (px - 1)) * VC + blk * 32 + lc * 8) * 2;
+      const unsigned f = (py == 0 ? 1u : 0u) | (py == 9 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == 17 ? 8u : 0u) |
+                         (pp >= 180 ? 16u : 0u);
+      pflag[i / 6] |= f << (5 * (i % 6));
+    }
+  }
   auto issue_tile = [&](int t, int bufsel) {
     const int bimg = t / (tiles_y * tiles_x);
     const int rem = t - bimg * tiles_y * tiles_x;
     const int y0 = (rem / tiles_x) * R, x0 = (rem % tiles_x) * 16;
-    char* const bb = smem + bufsel * BUF;
+    {                                                      // every tile lies inside the image (its halo may not): launcher
+      const unsigned out = (y0 == 0 ? 1u : 0u) | (y0 + R >= H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + 16 >= W ? 8u : 0u) | 16u;
+      const size_t pix0 = (size_t)(bimg * H + y0) * W + x0;
+      const char* const ub0 = (const char*)(ubase + pix0 * UC);   // wave-uniform tile bases
+      const char* const vb0 = (const char*)(vbase + pix0 * VC);
+      char* const bb = smem + bufsel * BUF;
+      const char* const zsrc = zeros + lc * 16;
 #pragma unroll
-    for (int i = 0; i < (NINSTR + NWV - 1) / NWV; ++i) {
-      const int j = wave + NWV * i;                        // wave-uniform
-      if (j >= NINSTR) break;
-      const char* src;
-      char* dst;
-      if (j < WU * 8) {
-        const int blk = j >> 3, r = j & 7;
-        const int gy = y0 + r, gx = x0 + lp;
-        const bool ok = gy < H && gx < W;
-        src = ok ? (const char*)(ubase + ((size_t)(bimg * H + gy) * W + gx) * UC + blk * 32 + lc * 8) : zeros + lc * 16;
-        dst = bb + blk * (NU * BLKP) + r * 1024;
-      } else {
+      for (int i = 0; i < NI; ++i) {
+        const int j = wave + NWV * i;                      // wave-uniform
+        if (j >= NINSTR) break;
+        const bool is_u = j < WU * 8;
         const int jj = j - WU * 8;
-        const int blk = jj / 12, ch = jj - blk * 12;
-        const int pp = ch * 16 + lp;
-        const int py = pp / 18, px = pp - py * 18;
-        const int gy = y0 + py - 1, gx = x0 + px - 1;
-        const bool ok = pp < 180 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        src = ok ? (const char*)(vbase + ((size_t)(bimg * H + gy) * W + gx) * VC + blk * 32 + lc * 8) : zeros + lc * 16;
-        dst = bb + UB + blk * (NV * BLKP) + ch * 1024;
+        char* const dst = is_u ? bb + (j >> 3) * (NU * BLKP) + (j & 7) * 1024
+                               : bb + UB + (jj / 12) * (NV * BLKP) + (jj % 12) * 1024;
+        const char* const base = is_u ? ub0 : vb0;
+        const bool bad = ((pflag[i / 6] >> (5 * (i % 6))) & out) != 0u;
+        const char* const src = bad ? zsrc : base + (ptrdiff_t)poff[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
 
@@ -410,8 +436,18 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
   if (t < ntiles) issue_tile(t, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // The two waves of a SIMD (w and w + NWV/2 of an eight-wave workgroup) issue the next tile's DMA at different points of
+  // the tile: the first half in front of its MFMAs, the second half behind the MFMAs of dz row WGRAD_STAGGER_ROW -- one
+  // wave's memory issue then runs beside its partner's matrix work instead of both queueing for the vector-memory pipe
+  // first and for the matrix pipe afterwards (same idea as the class A / B waves of conv_rs.hip)
+#ifndef WGRAD_STAGGER_ROW
+#define WGRAD_STAGGER_ROW 1
+#endif
+  constexpr int SROW = (NWV == 8) ? WGRAD_STAGGER_ROW : -1;
+  const bool late_issue = SROW >= 0 && wave >= NWV / 2;
   for (; t < ntiles; t += a.S) {
-    if (t + a.S < ntiles) issue_tile(t + a.S, cur ^ 1);    // DMA of the next tile flies under the MFMAs
+    const bool has_next = t + a.S < ntiles;
+    if (has_next && !late_issue) issue_tile(t + a.S, cur ^ 1);    // DMA of the next tile flies under the MFMAs
     if (computes) {
       unsigned xmask = 0xffu, rows_ok = R;
       if (PRO) {                                           // partial tiles: mask pixels outside the image
@@ -473,6 +509,10 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fur, fvr, acc[ti], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (r == SROW) {
+          if (has_next && late_issue) issue_tile(t + a.S, cur ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (PRO && r + 1 < R) {                  // the next dz row has arrived (only patch row r+3 is younger)
           asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
@@ -546,7 +586,9 @@ int launch_geo(const WgradArgs& a, hipStream_t st) {
   const bool wc2 = a.CD % 64 == 0;
   const bool wi2 = a.CA % 64 == 0 && a.CB % 64 == 0;
   if constexpr (GEO == 0 && sizeof(T) == 2) {
-    if (a.zeros) {           // bf16 3x3: LDS-DMA kernel (needs the caller's zero page)
+    // bf16 3x3: LDS-DMA kernel (needs the caller's zero page).  Its tile walk assumes whole 8 x 16 tiles (every U-Net /
+    // CLIP-decoder level: H % 8 == 0 and W % 16 == 0); other image sizes take the register-staged kernel below
+    if (a.zeros && a.H % 8 == 0 && a.W % 16 == 0) {
       if (segk_wgrad_wc(a.CD, a.CA, a.CB, 0, SEGK_DT_BF16) == 4) return launch_dma_pro<4, 2>(a, st);
       if (wc2 && wi2) return launch_dma_pro<2, 2>(a, st);
       if (wc2) return launch_dma_pro<2, 1>(a, st);
