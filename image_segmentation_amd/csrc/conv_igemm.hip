@@ -44,7 +44,7 @@ int segk_conv_use_pipe(int cin_p, int n_p, int dtype) {
   if (n_p % 64 == 0 && cin_p >= 128) return 64;
   return 0;
 }
-int segk_conv_writes_act(int cin_p, int n_p, int dtype) {
+int segk_conv_writes_act(int cin_p, int n_p, int dtype) {   // (conv_rs layers are a subset of these shapes)
   return segk_conv_use_ws(cin_p, n_p, dtype) || segk_conv_use_pipe(cin_p, n_p, dtype) != 0;
 }
 int segk_conv_bm(int geo, int unit) { return (unit % 128 == 0 || geo != 0) ? 256 : 128; }

@@ -603,3 +603,4 @@ def test_biased_conv_on_rs_shape_falls_through_to_ws_and_refuses_statistics(ops)
     assert rc == -2 and b"bias together with BatchNorm statistics" in _lib.load().segk_last_error()
     torch.cuda.synchronize()
     assert float(st.abs().sum()) == 0.0                                           # nothing was launched
+

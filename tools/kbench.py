@@ -14,6 +14,12 @@ LAYERS = [  # name, Cin, Cout, HW   (B = 32)
     ("64->64@256", 64, 64, 256), ("128->64@256", 128, 64, 256), ("64->128@256(dgrad up4)", 64, 128, 256),
     ("128->128@128", 128, 128, 128), ("256->256@64", 256, 256, 64), ("512->512@32", 512, 512, 32),
     ("1024->1024@16", 1024, 1024, 16), ("3->64@256", 32, 64, 256),
+    # the Cin != Cout layers of the U-Net (first conv of each block and the data gradients of those)
+    ("64->128@128", 64, 128, 128), ("128->256@64", 128, 256, 64), ("256->512@32", 256, 512, 32), ("512->1024@16", 512, 1024, 16),
+    ("1024->512@32", 1024, 512, 32), ("512->256@64", 512, 256, 64), ("256->128@128", 256, 128, 128),
+    ("128->64@128(dgrad)", 128, 64, 128), ("256->128@64(dgrad)", 256, 128, 64), ("512->256@32(dgrad)", 512, 256, 32),
+    ("1024->512@16(dgrad)", 1024, 512, 16), ("512->1024@32(dgrad)", 512, 1024, 32), ("256->512@64(dgrad)", 256, 512, 64),
+    ("128->256@128(dgrad)", 128, 256, 128),
 ]
 
 

@@ -32,7 +32,7 @@ def short(name):
 
 
 def family(name):
-    if any(t in name for t in ("conv3x3_pipe", "conv_ws_kernel", "conv_rs_kernel", "stem_stream_kernel", "conv_rk_kernel")):
+    if any(t in name for t in ("conv3x3_pipe", "conv_ws_kernel", "conv_rs_kernel", "stem_stream_kernel")):
         return "conv3x3"
     if "convt_stream_kernel" in name:
         return "conv_other"
