@@ -604,3 +604,4 @@ def test_biased_conv_on_rs_shape_falls_through_to_ws_and_refuses_statistics(ops)
     torch.cuda.synchronize()
     assert float(st.abs().sum()) == 0.0                                           # nothing was launched
 
+
