@@ -19,7 +19,7 @@ _vp, _fp, _i, _l, _f, _d = C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float,
 SIGNATURES = {
     "segk_version": (_i, []),
     "segk_entry_count": (_i, []),
-    "segk_clock_probe": (_i, [_vp, _i, _i, _vp]),
+    "segk_clock_probe": (_i, [_vp, _i, _i, _i, _vp]),
     "segk_build_id": (C.c_char_p, []),
     "segk_last_error": (C.c_char_p, []),
     "segk_nchw_to_nhwc": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -39,7 +39,7 @@ int segk_loss_bwd_impl(const float*, const long long*, const float*, const float
 int segk_prompt_mix_impl(const float*, const float*, const float*, float*, int, long, hipStream_t);
 int segk_confusion_impl(const float*, const long long*, int, int, long, unsigned long long*, hipStream_t);
 
-int segk_clock_probe_impl(unsigned long long*, int, int, hipStream_t);
+int segk_clock_probe_impl(unsigned long long*, int, int, int, hipStream_t);
 
 int segk_device_index() {
   int dev = 0;
@@ -67,8 +67,8 @@ extern "C" {
 #endif
 int segk_version(void) { return SEGK_ABI_VERSION; }
 int segk_entry_count(void) { return SEGK_ENTRY_COUNT; }
-int segk_clock_probe(uint64_t* out, int blocks, int iters, segk_stream_t s) {
-  return segk_clock_probe_impl((unsigned long long*)out, blocks, iters, (hipStream_t)s);
+int segk_clock_probe(uint64_t* out, int blocks, int iters, int shape, segk_stream_t s) {
+  return segk_clock_probe_impl((unsigned long long*)out, blocks, iters, shape, (hipStream_t)s);
 }
 const char* segk_build_id(void) { return SEGK_BUILD_ID; }
 const char* segk_last_error(void) { return g_segk_err; }

@@ -410,28 +410,26 @@ class _level_scope:
 
 def clock_probe(launches=4, blocks=256, iters=20000, device=None):
     """Median shader clock (GHz) the chip holds under a dense bf16 MFMA probe (segk_clock_probe: `launches` back-to-back
-    launches of `iters` x 16 MFMAs per wave, the last one evaluated).  Diagnostic only: a number that explains box-to-box
-    spread of the MFMA-bound kernels; it synchronises the device."""
+    launches of `iters` rounds per wave, the last one evaluated), for both MFMA shapes the kernels use.  Diagnostic only:
+    numbers that explain box-to-box spread of the MFMA-bound kernels; it synchronises the device."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    out = torch.zeros((blocks * 4 * 2,), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
-        for _ in range(launches):
-            _lib.call("segk_clock_probe", out.data_ptr(), blocks, iters, _stream())
-        torch.cuda.synchronize(dev)
-    t = out.view(-1, 2).double().cpu()
-    ghz = (t[:, 0] / t[:, 1].clamp(min=1.0)) * 0.1
-    return {"median_ghz": round(float(ghz.median()), 4), "min_ghz": round(float(ghz.min()), 4),
-            "max_ghz": round(float(ghz.max()), 4), "probe_ms": round(float(t[:, 1].median()) / 1e5, 3),
-            "method": f"s_memtime / s_memrealtime (100 MHz) around {iters} x 16 v_mfma_f32_32x32x16_bf16 per wave, one wave "
-                      f"per SIMD on {blocks} workgroups, launch {launches} of {launches} back to back"}
-
-
-def _span(tag, flops=0.0, nbytes=0.0):
-    return _NOSPAN if TIMER is None else TIMER.span(tag, flops, nbytes)
-
-
-def _es(dtype):
-    return 2 if dtype == torch.bfloat16 else 4
+    res = {"method": f"s_memtime / s_memrealtime (100 MHz) around {iters} rounds of 16 v_mfma_f32_32x32x16_bf16 (or 32 "
+                     f"v_mfma_f32_16x16x32_bf16: the same matrix work) per wave, one wave per SIMD on {blocks} workgroups, "
+                     f"launch {launches} of {launches} back to back; pseudo-random register operands"}
+    for shape, name in ((0, "mfma_32x32x16"), (1, "mfma_16x16x32")):
+        out = torch.zeros((blocks * 4 * 2,), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            for _ in range(launches):
+                _lib.call("segk_clock_probe", out.data_ptr(), blocks, iters, shape, _stream())
+            torch.cuda.synchronize(dev)
+        t = out.view(-1, 2).double().cpu()
+        ghz = (t[:, 0] / t[:, 1].clamp(min=1.0)) * 0.1
+        ms = float(t[:, 1].median()) / 1e5
+        res[name] = {"median_ghz": round(float(ghz.median()), 4), "min_ghz": round(float(ghz.min()), 4),
+                     "max_ghz": round(float(ghz.max()), 4), "probe_ms": round(ms, 3),
+                     "probe_pflops": round(blocks * 4 * iters * 16 * 32768.0 / (ms * 1e-3) / 1e15, 3)}
+    res["median_ghz"] = res["mfma_32x32x16"]["median_ghz"]
+    return res
 
 
 # ------------------------------------------------------------------------------------------------

@@ -294,10 +294,10 @@ int segk_prob_loss_bwd(const float* probs, const int64_t* labels, const float* c
 
 /* ---- diagnostics (not on the product path) ---------------------------------------------------------
  * The shader clock held under a dense bf16 MFMA load: `blocks` workgroups of four waves (one per SIMD) run `iters` rounds of
- * 16 v_mfma_f32_32x32x16_bf16 each and write, per wave w, out[2w] = elapsed shader cycles (s_memtime) and out[2w+1] =
+ * 16 v_mfma_f32_32x32x16_bf16 (shape 0; shape 1: the same work as 32 v_mfma_f32_16x16x32_bf16) each and write, per wave w, out[2w] = elapsed shader cycles (s_memtime) and out[2w+1] =
  * elapsed ticks of the constant 100 MHz counter (s_memrealtime): clock = out[2w] / out[2w+1] x 100 MHz.  bench.py puts
  * the median into its line so that box-to-box spread is explained by a number. */
-int segk_clock_probe(uint64_t* out, int blocks, int iters, segk_stream_t s);
+int segk_clock_probe(uint64_t* out, int blocks, int iters, int shape, segk_stream_t s);
 
 /* ---- metric: argmax + confusion matrix (utils/MetricsHistory.py:65-75) ---------------------------
  * M[pred*8 + label] += count (uint64, caller zeroes); TP/FP/FN/TN follow on the host. */
