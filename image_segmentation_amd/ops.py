@@ -432,6 +432,14 @@ def clock_probe(launches=4, blocks=256, iters=20000, device=None):
     return res
 
 
+def _span(tag, flops=0.0, nbytes=0.0):
+    return _NOSPAN if TIMER is None else TIMER.span(tag, flops, nbytes)
+
+
+def _es(dtype):
+    return 2 if dtype == torch.bfloat16 else 4
+
+
 # ------------------------------------------------------------------------------------------------
 # thin wrappers over the C ABI (all asynchronous on the current stream)
 def _f32(n, dev):

@@ -32,3 +32,34 @@ def test_pmc_post_names_kernel_families():
     assert m.family("void (anonymous namespace)::wgrad_dma_kernel<4, 2, false>(WgradArgs)") == "wgrad3x3"
     assert m.family("_ZN12_GLOBAL__N_112wgrad_kernelIDF16bLi2ELi4ELi2EEEv9WgradArgs") == "wgrad_other"
     assert m.family("void at::native::vectorized_elementwise_kernel<4>(int)") is None
+
+
+def test_no_undefined_names_in_product_python():
+    """A static pass over the package and bench.py: every name that is read is bound somewhere in its module (assignment,
+    def, class, import, argument, loop / comprehension / with / except target) or is a builtin.  Catches a helper deleted by
+    an edit (a NameError that only a GPU run would otherwise show)."""
+    import ast
+    import builtins
+    files = sorted(glob.glob(os.path.join(ROOT, "image_segmentation_amd", "*.py"))) + [os.path.join(ROOT, "bench.py"),
+                                                                                       os.path.join(ROOT, "__graft_entry__.py")]
+    for path in files:
+        tree = ast.parse(open(path).read(), path)
+        bound = set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                bound.add(node.name)
+            if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda)):
+                a = node.args
+                for arg in a.posonlyargs + a.args + a.kwonlyargs + ([a.vararg] if a.vararg else []) + ([a.kwarg] if a.kwarg else []):
+                    bound.add(arg.arg)
+            elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+                bound.add(node.id)
+            elif isinstance(node, (ast.Import, ast.ImportFrom)):
+                for al in node.names:
+                    bound.add((al.asname or al.name).split(".")[0])
+            elif isinstance(node, ast.ExceptHandler) and node.name:
+                bound.add(node.name)
+            elif isinstance(node, (ast.Global, ast.Nonlocal)):
+                bound.update(node.names)
+        missing = sorted({n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)} - bound)
+        assert not missing, (os.path.relpath(path, ROOT), missing)
