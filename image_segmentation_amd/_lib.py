@@ -45,6 +45,7 @@ SIGNATURES = {
     "segk_wgrad_split": (_i, [_i, _i, _i, _i, _i, _i]),
     "segk_wgrad": (_i, [_vp, _vp, _vp, _fp, _fp, _fp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "segk_wgrad_reduce": (_i, [_fp, _i, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "segk_wgrad_reduce_multi": (_i, [_vp, _i, _vp]),
     "segk_bn_finalize": (_i, [_fp, _i, _i, _i, _d, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _fp, _fp, _fp, _fp, _vp]),
     "segk_bn_relu_apply": (_i, [_vp, _vp, _fp, _fp, _l, _i, _i, _vp]),
     "segk_bn_relu_apply_pool": (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
@@ -77,14 +78,22 @@ SIGNATURES = {
     "segk_head_bwd_bnstat": (_i, [_fp, _vp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _vp]),
     "segk_loss_part_floats": (_i, [_l]),
     "segk_loss_state_floats": (_i, []),
-    "segk_loss_fwd": (_i, [_fp, _vp, _fp, _i, _i, _l, _i, _f, _f, _f, _fp, _fp, _vp]),
+    "segk_loss_fwd": (_i, [_fp, _vp, _fp, _i, _i, _l, _i, _f, _f, _f, _fp, _fp, _fp, _vp]),
     "segk_loss_bwd": (_i, [_fp, _vp, _fp, _fp, _fp, _i, _i, _l, _i, _f, _f, _fp, _vp]),
     "segk_prompt_mix_fwd": (_i, [_fp, _fp, _fp, _i, _l, _vp]),
     "segk_prompt_mix_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _l, _vp]),
-    "segk_prob_loss_fwd": (_i, [_fp, _vp, _fp, _i, _i, _l, _i, _f, _f, _f, _i, _f, _fp, _fp, _vp]),
+    "segk_prob_loss_fwd": (_i, [_fp, _vp, _fp, _i, _i, _l, _i, _f, _f, _f, _i, _f, _fp, _fp, _fp, _vp]),
     "segk_prob_loss_bwd": (_i, [_fp, _vp, _fp, _fp, _fp, _i, _i, _l, _i, _f, _f, _i, _f, _fp, _vp]),
     "segk_confusion": (_i, [_fp, _vp, _i, _i, _l, _vp, _vp]),
 }
+
+
+
+class ReduceJob(C.Structure):
+    """segk_reduce_job of include/segk.h (one reduction of segk_wgrad_reduce_multi)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("kind", C.c_int), ("S", C.c_int), ("N", C.c_int), ("CA", C.c_int),
+                ("CB", C.c_int), ("Np", C.c_int), ("CAp", C.c_int), ("CBp", C.c_int), ("taps", C.c_int), ("pad_", C.c_int)]
+
 
 _lib = None
 

@@ -27,13 +27,14 @@ int segk_pack_conv3x3_both_impl(const float*, void*, void*, int, int, int, int, 
 int segk_pack_multi_impl(const void*, int, int, int, hipStream_t);
 int segk_pack_convt_chunk_impl();
 int segk_wgrad_reduce_impl(const float*, int, float*, int, int, int, int, int, int, int, hipStream_t);
+int segk_wgrad_reduce_multi_impl(const segk_reduce_job*, int, hipStream_t);
 int segk_head_fwd_impl(const void*, const float*, const float*, float*, int, int, int, int, int, int, const float*, const float*,
                        int, hipStream_t);
 int segk_head_bwd_impl(const float*, const void*, const float*, void*, float*, float*, float*, int, int, int, int, int,
                        int, const float*, const float*, const float*, const float*, float*, int, int, hipStream_t);
 int segk_head_blocks_q(long);
 int segk_loss_fwd_impl(const float*, const long long*, const float*, int, int, long, int, float, float, float, float*,
-                       float*, int, int, float, hipStream_t);
+                       float*, float*, int, int, float, hipStream_t);
 int segk_loss_bwd_impl(const float*, const long long*, const float*, const float*, const float*, int, int, long, int,
                        float, float, float*, int, int, float, hipStream_t);
 int segk_prompt_mix_impl(const float*, const float*, const float*, float*, int, long, hipStream_t);
@@ -227,6 +228,9 @@ int segk_wgrad_reduce(const float* slabs, int S, float* grad, int N, int CA, int
                       segk_stream_t s) {
   return segk_wgrad_reduce_impl(slabs, S, grad, N, CA, CB, Np, CAp, CBp, taps, (hipStream_t)s);
 }
+int segk_wgrad_reduce_multi(const segk_reduce_job* jobs, int n, segk_stream_t s) {
+  return segk_wgrad_reduce_multi_impl(jobs, n, (hipStream_t)s);
+}
 
 int segk_bn_finalize(const float* stats, int tiles, int Cp, int C, double count, const float* conv_bias,
                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
@@ -311,15 +315,16 @@ int segk_head_bwd_bn(const float* dlogits, const void* z, const float* w, void* 
                             (hipStream_t)s);
 }
 int segk_loss_fwd(const float* logits, const int64_t* labels, const float* cw, int N, int C, long HW, int ignore_index,
-                  float smooth, float dice_weight, float ce_weight, float* part, float* state, segk_stream_t s) {
+                  float smooth, float dice_weight, float ce_weight, float* part, float* state, float* loss_out,
+                  segk_stream_t s) {
   return segk_loss_fwd_impl(logits, (const long long*)labels, cw, N, C, HW, ignore_index, smooth, dice_weight, ce_weight,
-                            part, state, 0, 0, 0.f, (hipStream_t)s);
+                            part, state, loss_out, 0, 0, 0.f, (hipStream_t)s);
 }
 int segk_prob_loss_fwd(const float* probs, const int64_t* labels, const float* cw, int N, int C, long HW, int ignore_index,
                        float smooth, float dice_weight, float nll_weight, int nll_log, float eps, float* part, float* state,
-                       segk_stream_t s) {
+                       float* loss_out, segk_stream_t s) {
   return segk_loss_fwd_impl(probs, (const long long*)labels, cw, N, C, HW, ignore_index, smooth, dice_weight, nll_weight,
-                            part, state, 1, nll_log, eps, (hipStream_t)s);
+                            part, state, loss_out, 1, nll_log, eps, (hipStream_t)s);
 }
 int segk_prob_loss_bwd(const float* probs, const int64_t* labels, const float* cw, const float* state, const float* gout,
                        int N, int C, long HW, int ignore_index, float dice_weight, float nll_weight, int nll_log, float eps,

@@ -10,42 +10,11 @@
 #include <atomic>
 #include "common.hpp"
 #include "segk_internal.h"
+#include "ticket.hpp"
 #include "../../include/segk.h"
 
 namespace {
-// ---------------------------------------------------------------------------------------------
-// In-launch hand-off from the blocks of one reduction to the block that finishes it (instead of a second, tiny kernel):
-// every block publishes its partials and draws a ticket; the block that draws the last one reads them all.  One counter
-// per (slot, group); a launch takes the next slot (host side, round robin), the finishing block resets its counter, so
-// a slot is clean again long before the ring of slots comes back to it.  Agent-scope release / acquire around a relaxed
-// ticket (cdna_hip_programming.md, in-launch split-K reduction): correct wherever the blocks run.
-constexpr int TICKET_SLOTS = 256, TICKET_GROUPS = 32;
 __device__ unsigned g_tickets[TICKET_SLOTS * TICKET_GROUPS];     // zero at module load
-inline int next_ticket_slot() {
-  static std::atomic<unsigned> n{0};
-  return (int)(n.fetch_add(1, std::memory_order_relaxed) % TICKET_SLOTS);
-}
-// true in every thread of the block that arrives LAST of `n` at `counter` (the caller's global stores are published
-// first; the last block may then read every other block's).  flag: one int of LDS nobody else touches across the call.
-__device__ __forceinline__ bool last_arriver(unsigned* counter, unsigned n, volatile int* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == n - 1) ? 1 : 0;
-    if (last) {
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    *flag = last;
-  }
-  __syncthreads();
-  return *flag != 0;
-}
-
 
 // block = CVB channel-vectors x ROWS pixel lanes (CVB*ROWS <= 256); grid.y covers channel blocks.
 struct Lanes {
@@ -631,6 +600,14 @@ static inline void lane_geometry(int C, int vec, int* cvb, int* rows, int* gy) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+unsigned* segk_ticket_slot() {
+  static std::atomic<unsigned> n{0};
+  static unsigned* base[SEGK_MAX_DEVICES] = {};      // per device: the symbol lives in that device's module image
+  const int dev = segk_device_index();
+  if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
+  return base[dev] + (size_t)(n.fetch_add(1, std::memory_order_relaxed) % TICKET_SLOTS) * TICKET_GROUPS;
+}
+
 int segk_bn_finalize_impl(const float* part, int MT, int C, int C_real, double count, const float* conv_bias,
                           const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
                           int training, float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
@@ -648,11 +625,8 @@ int segk_bn_finalize_impl(const float* part, int MT, int C, int C_real, double c
   }
   if (training) {
     SEGK_REQUIRE(C / 32 <= TICKET_GROUPS, "bn_finalize: at most %d channels", 32 * TICKET_GROUPS);
-    static unsigned* ticket_base[SEGK_MAX_DEVICES] = {};      // per device: the symbol lives in that device's module image
-    const int dev = segk_device_index();
-    if (!ticket_base[dev] && hipGetSymbolAddress((void**)&ticket_base[dev], HIP_SYMBOL(g_tickets)) != hipSuccess)
-      SEGK_FAIL(-3, "bn_finalize: no ticket array");
-    unsigned* tickets = ticket_base[dev] + (size_t)next_ticket_slot() * TICKET_GROUPS;
+    unsigned* const tickets = segk_ticket_slot();
+    SEGK_REQUIRE(tickets != nullptr, "bn_finalize: no ticket array");
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 32, NCH), dim3(256), 0, st, part, MT, C, C_real, count, conv_bias,
                        gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean, rstd, scratch, tickets);
     SEGK_CHECK_LAUNCH("bn_stats_finalize");

@@ -12,6 +12,7 @@
 #include <type_traits>
 #include "common.hpp"
 #include "segk_internal.h"
+#include "ticket.hpp"
 #include "../../include/segk.h"
 
 namespace {
@@ -277,63 +278,12 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// PROB: the input already holds class probabilities (prompt model, prompt_based/prompt.py:33-56): Dice on the values
-// themselves (weighted_loss.py:206-209 with apply_softmax=False) and NLLLoss on nll_nonlin(x) = log(x + eps)
-// (nll_log, prompt.ipynb's stable_log) or on x itself (weighted_loss.py:338-340)
-template <bool PROB>
-__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ logits,
-                                                       const long long* __restrict__ labels,
-                                                       const float* __restrict__ cw, long P, long HW, int C,
-                                                       int ignore_index, float* __restrict__ part, int nll_log, float eps) {
-  __shared__ float sh[4];
-  float acc[LP];
-#pragma unroll
-  for (int i = 0; i < LP; ++i) acc[i] = 0.f;
-  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
-    const long b = p / HW, r = p - b * HW;
-    float l[MAXC], raw[MAXC], m = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      raw[k] = (k < C) ? logits[(b * C + k) * HW + r] : -INFINITY;
-      m = fmaxf(m, raw[k]);
-    }
-    float se = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      if constexpr (PROB) l[k] = (k < C) ? raw[k] : 0.f;
-      else l[k] = (k < C) ? expf(raw[k] - m) : 0.f;
-      se += l[k];
-    }
-    const float inv = PROB ? 1.f : 1.f / se, lse = PROB ? 0.f : logf(se);
-    const long long y = labels[p];
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      const float pk = l[k] * inv;
-      const float oh = (y == k) ? 1.f : 0.f;
-      acc[2 + k] += pk * oh;
-      acc[2 + MAXC + k] += pk;
-      acc[2 + 2 * MAXC + k] += oh;
-      if (y == k && k < C && y != ignore_index) {
-        const float wy = cw ? cw[k] : 1.f;
-        if constexpr (PROB) acc[0] += wy * (nll_log ? -logf(raw[k] + eps) : -raw[k]);
-        else acc[0] += wy * (lse - (raw[k] - m));   // -log softmax = log(sum exp) - (logit - max)
-        acc[1] += wy;
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < LP; ++i) {
-    const float s = block_sum(acc[i], sh);
-    if (threadIdx.x == 0) part[(size_t)blockIdx.x * LP + i] = s;
-  }
-}
-
 // state: [0]=loss [1]=ce [2]=dice(-mean dc) [3]=ce_den, [4..4+MAXC) dc, [.. ) den_raw(Sp+Sg+smooth), [..) a_k
 constexpr int LS = 4 + 3 * MAXC;
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int NB, int C,
-                                                            const float* cw, int ignore_index, float smooth,
-                                                            float dice_weight, float ce_weight,
-                                                            float* __restrict__ state) {
+// runs in ONE block of 256 threads: the block of loss_fwd_kernel that finished last (ticket.hpp)
+__device__ __forceinline__ void loss_finalize_block(const float* __restrict__ part, int NB, int C, const float* cw,
+                                                    int ignore_index, float smooth, float dice_weight, float ce_weight,
+                                                    float* __restrict__ state, float* __restrict__ loss_out) {
   __shared__ double tot[LP];
   __shared__ double sh[8][32];
   static_assert(LP <= 32, "one column lane per partial");
@@ -384,11 +334,71 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     state[4 + 2 * MAXC + k] = valid ? (float)((cw ? (double)cw[k] : 1.0) / wsum) : 0.f;
   }
   state[0] = (float)((double)dice_weight * dice + (double)ce_weight * ce);
+  if (loss_out) *loss_out = state[0];
   state[1] = (float)ce;
   state[2] = (float)dice;
   state[3] = (float)tot[1];
   (void)nvalid;
 }
+
+// PROB: the input already holds class probabilities (prompt model, prompt_based/prompt.py:33-56): Dice on the values
+// themselves (weighted_loss.py:206-209 with apply_softmax=False) and NLLLoss on nll_nonlin(x) = log(x + eps)
+// (nll_log, prompt.ipynb's stable_log) or on x itself (weighted_loss.py:338-340)
+template <bool PROB>
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ logits,
+                                                       const long long* __restrict__ labels,
+                                                       const float* __restrict__ cw, long P, long HW, int C,
+                                                       int ignore_index, float* __restrict__ part, int nll_log, float eps,
+                                                       float smooth, float dice_weight, float ce_weight,
+                                                       float* __restrict__ state, float* __restrict__ loss_out,
+                                                       unsigned* __restrict__ ticket) {
+  __shared__ float sh[4];
+  __shared__ int last;
+  float acc[LP];
+#pragma unroll
+  for (int i = 0; i < LP; ++i) acc[i] = 0.f;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    const long b = p / HW, r = p - b * HW;
+    float l[MAXC], raw[MAXC], m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      raw[k] = (k < C) ? logits[(b * C + k) * HW + r] : -INFINITY;
+      m = fmaxf(m, raw[k]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      if constexpr (PROB) l[k] = (k < C) ? raw[k] : 0.f;
+      else l[k] = (k < C) ? expf(raw[k] - m) : 0.f;
+      se += l[k];
+    }
+    const float inv = PROB ? 1.f : 1.f / se, lse = PROB ? 0.f : logf(se);
+    const long long y = labels[p];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const float pk = l[k] * inv;
+      const float oh = (y == k) ? 1.f : 0.f;
+      acc[2 + k] += pk * oh;
+      acc[2 + MAXC + k] += pk;
+      acc[2 + 2 * MAXC + k] += oh;
+      if (y == k && k < C && y != ignore_index) {
+        const float wy = cw ? cw[k] : 1.f;
+        if constexpr (PROB) acc[0] += wy * (nll_log ? -logf(raw[k] + eps) : -raw[k]);
+        else acc[0] += wy * (lse - (raw[k] - m));   // -log softmax = log(sum exp) - (logit - max)
+        acc[1] += wy;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LP; ++i) {
+    const float s = block_sum(acc[i], sh);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * LP + i] = s;
+  }
+  // the block that finishes last turns the partial rows into the loss (no second launch, nobody waits)
+  if (last_arriver(ticket, gridDim.x, &last))
+    loss_finalize_block(part, (int)gridDim.x, C, cw, ignore_index, smooth, dice_weight, ce_weight, state, loss_out);
+}
+
 
 template <bool PROB>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits,
@@ -640,16 +650,16 @@ int segk_loss_state_floats(void) { return LS; }
 
 int segk_loss_fwd_impl(const float* logits, const long long* labels, const float* cw, int N, int C, long HW,
                        int ignore_index, float smooth, float dice_weight, float ce_weight, float* part, float* state,
-                       int prob, int nll_log, float eps, hipStream_t st) {
+                       float* loss_out, int prob, int nll_log, float eps, hipStream_t st) {
   SEGK_REQUIRE(logits && labels && part && state && N > 0 && HW > 0, "loss_fwd: bad arguments");
   SEGK_REQUIRE(C >= 1 && C <= MAXC, "loss_fwd: 1..%d classes supported, got %d", MAXC, C);
   const long P = (long)N * HW;
   const int nb = segk_loss_blocks(P);
-  if (prob) hipLaunchKernelGGL(loss_fwd_kernel<true>, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part, nll_log, eps);
-  else hipLaunchKernelGGL(loss_fwd_kernel<false>, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part, 0, 0.f);
+  unsigned* const ticket = segk_ticket_slot();
+  SEGK_REQUIRE(ticket != nullptr, "loss_fwd: no ticket array");
+  if (prob) hipLaunchKernelGGL(loss_fwd_kernel<true>, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part, nll_log, eps, smooth, dice_weight, ce_weight, state, loss_out, ticket);
+  else hipLaunchKernelGGL(loss_fwd_kernel<false>, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part, 0, 0.f, smooth, dice_weight, ce_weight, state, loss_out, ticket);
   SEGK_CHECK_LAUNCH("loss_fwd");
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, nb, C, cw, ignore_index, smooth, dice_weight, ce_weight, state);
-  SEGK_CHECK_LAUNCH("loss_finalize");
   return 0;
 }
 

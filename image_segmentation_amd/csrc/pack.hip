@@ -4,6 +4,7 @@
 // All tiny, bandwidth-trivial; one thread per destination element.
 #include "common.hpp"
 #include "segk_internal.h"
+#include "../../include/segk.h"
 
 namespace {
 
@@ -198,12 +199,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const SegkPackEntry* __
 // Sum S gradient slabs [S][Np][taps][Kp] (fp32) into the dense reference-layout gradient [N][K][taps]
 // (OIHW for Conv2d, IOHW for ConvTranspose2d).  One block per output row n: the slab rows are read with
 // coalesced float4 loads (k fastest), transposed through LDS, and the row is written as one contiguous run.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int S,
-                                                           float* __restrict__ grad, int N, int CA, int CB, int Np,
-                                                           int CAp, int CBp, int taps) {
-  extern __shared__ float row[];                 // [K][taps] in output order
+// One output row n of the gradient: sum the S slabs in slab order (bit-stable), transpose [tap][k] -> [k][tap] through LDS
+__device__ __forceinline__ void wgrad_reduce_row(const float* __restrict__ slabs, int S, float* __restrict__ grad, int n, int CA,
+                                                 int CB, int Np, int CAp, int CBp, int taps, float* row) {
   const int Kp = CAp + CBp, K = CA + CB;
-  const int n = blockIdx.x;
   const long slab = (long)Np * taps * Kp;
   const float* base = slabs + (long)n * taps * Kp;
   const int nvec = taps * Kp / 4;                // Kp % 32 == 0
@@ -226,20 +225,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   float* dst = grad + (long)n * K * taps;
   for (int i = threadIdx.x; i < K * taps; i += 256) dst[i] = row[i];
 }
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int S,
+                                                           float* __restrict__ grad, int N, int CA, int CB, int Np,
+                                                           int CAp, int CBp, int taps) {
+  extern __shared__ float row[];                 // [K][taps] in output order
+  wgrad_reduce_row(slabs, S, grad, blockIdx.x, CA, CB, Np, CAp, CBp, taps, row);
+}
 
 // The same sum for MANY thin slabs (narrow layers: split-K factors of 64 .. 512 over a gradient of a few hundred KB), in
 // one launch: a block owns 16 float4 vectors of one output row and walks the slabs in 16 interleaved streams
 // (thread = vector lane x slab lane), then adds the 16 stream sums in lane order (fixed order: bit-stable) and scatters the
 // 64 values to their [k][tap] places.
-__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ slabs, int S,
-                                                                float* __restrict__ grad, int N, int CA, int CB, int Np,
-                                                                int CAp, int CBp, int taps) {
-  __shared__ float4 red[16][16];
+__device__ __forceinline__ void wgrad_reduce_wide(const float* __restrict__ slabs, int S, float* __restrict__ grad, int n, int vy,
+                                                  int CA, int CB, int Np, int CAp, int CBp, int taps, float4 (&red)[16][16]) {
   const int Kp = CAp + CBp, K = CA + CB;
-  const int n = blockIdx.x;
   const int vl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int nvec = taps * Kp / 4;
-  const int v = blockIdx.y * 16 + vl;
+  const int v = vy * 16 + vl;
   const long slab = (long)Np * taps * Kp;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (v < nvec) {
@@ -265,6 +267,63 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
     const int q = kp + j;
     const int k = q < CAp ? (q < CA ? q : -1) : (q - CAp < CB ? CA + q - CAp : -1);
     if (k >= 0) dst[k * taps + tap] = vals[j];
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ slabs, int S,
+                                                                float* __restrict__ grad, int N, int CA, int CB, int Np,
+                                                                int CAp, int CBp, int taps) {
+  __shared__ float4 red[16][16];
+  wgrad_reduce_wide(slabs, S, grad, blockIdx.x, blockIdx.y, CA, CB, Np, CAp, CBp, taps, red);
+}
+
+// Column sums of BatchNorm-style partial rows: out[c] = sum over rows of part[row][col0 + c][0] (stride 2 floats per
+// channel): the ConvTranspose bias gradient taken from the concat data-gradient's per-tile channel sums.  One block per 32
+// channels, 8 row lanes, fp64, fixed order.
+__device__ __forceinline__ void colsum_block(const float* __restrict__ part, int rows, int Ctot, int col0, int C,
+                                             float* __restrict__ out, int cb, double (&sh)[8][32]) {
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = cb * 32 + cx;
+  double s = 0.0;
+  if (c < C)
+    for (int r = ry; r < rows; r += 8) s += (double)part[((size_t)r * Ctot + col0 + c) * 2];
+  sh[ry][cx] = s;
+  __syncthreads();
+  if (ry != 0 || c >= C) return;
+  s = 0.0;
+  for (int r = 0; r < 8; ++r) s += sh[r][cx];
+  out[c] = (float)s;
+}
+
+// Up to four of the reductions above in ONE launch (the weight gradients of a DoubleConv block, the ConvTranspose weight
+// gradient of an Up block and its bias gradient): the jobs travel by value in the kernel arguments; a block finds its job
+// by its first block index.  Results are bit-identical to the single-job launches.
+struct ReduceJob {
+  const float* src;     // slabs | partial rows
+  float* dst;           // gradient | column sums
+  int S, N, CA, CB, Np, CAp, CBp, taps;     // kind 2: S = rows, N = total channels of a row, CA = first column, CB = columns
+  int kind;             // 0: row form, 1: slab-parallel form, 2: column sums
+  int block0, ny;       // first block of the job; kind 1: blocks per output row
+  int pad_;
+};
+struct ReduceJobs {
+  ReduceJob j[4];
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const ReduceJobs p) {
+  extern __shared__ float row[];
+  __shared__ float4 red[16][16];
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < p.n && (int)blockIdx.x >= p.j[i].block0) ji = i;
+  const ReduceJob& jb = p.j[ji];
+  const int local = blockIdx.x - jb.block0;
+  if (jb.kind == 0) {
+    wgrad_reduce_row(jb.src, jb.S, jb.dst, local, jb.CA, jb.CB, jb.Np, jb.CAp, jb.CBp, jb.taps, row);
+  } else if (jb.kind == 1) {
+    wgrad_reduce_wide(jb.src, jb.S, jb.dst, local / jb.ny, local % jb.ny, jb.CA, jb.CB, jb.Np, jb.CAp, jb.CBp, jb.taps, red);
+  } else {
+    colsum_block(jb.src, jb.S, jb.N, jb.CA, jb.CB, jb.dst, local, *(double(*)[8][32])red);
   }
 }
 
@@ -358,6 +417,57 @@ int segk_pack_convt_weight_impl(const float* w, void* dst, int Cin, int Cout, in
     hipLaunchKernelGGL(pack_convt_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, w, (float*)dst, Cin,
                        Cout, Cinp, Coutp, mode);
   SEGK_CHECK_LAUNCH("pack_convt_weight");
+  return 0;
+}
+
+// jobs: host array of n <= 4 segk_reduce_job (include/segk.h); see wgrad_reduce_multi_kernel
+int segk_wgrad_reduce_multi_impl(const segk_reduce_job* jobs, int n, hipStream_t st) {
+  SEGK_REQUIRE(jobs && n >= 1 && n <= 4, "wgrad_reduce_multi: 1..4 jobs");
+  ReduceJobs p{};
+  p.n = n;
+  int blocks = 0;
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const segk_reduce_job& q = jobs[i];
+    ReduceJob& r = p.j[i];
+    r.src = q.src; r.dst = q.dst; r.block0 = blocks; r.ny = 1;
+    SEGK_REQUIRE(q.src && q.dst, "wgrad_reduce_multi: job %d: null pointer", i);
+    if (q.kind == 0) {        // weight-gradient slabs
+      SEGK_REQUIRE(q.S > 0 && q.N > 0 && q.CA > 0 && q.CB >= 0 && q.Np >= q.N && q.CAp >= q.CA && q.CBp >= q.CB && q.taps > 0 &&
+                       (q.CAp + q.CBp) % 32 == 0,
+                   "wgrad_reduce_multi: job %d: bad arguments", i);
+      r.S = q.S; r.N = q.N; r.CA = q.CA; r.CB = q.CB; r.Np = q.Np; r.CAp = q.CAp; r.CBp = q.CBp; r.taps = q.taps;
+      if (q.S > 16) {
+        r.kind = 1;
+        r.ny = (q.taps * (q.CAp + q.CBp) / 4 + 15) / 16;
+        blocks += q.N * r.ny;
+      } else {
+        r.kind = 0;
+        const size_t need = (size_t)(q.CA + q.CB) * q.taps * sizeof(float);
+        SEGK_REQUIRE(need <= 64 * 1024, "wgrad_reduce_multi: a gradient row of %zu bytes exceeds the LDS staging limit", need);
+        if (need > lds) lds = need;
+        blocks += q.N;
+      }
+    } else if (q.kind == 1) { // column sums of partial rows
+      SEGK_REQUIRE(q.S > 0 && q.N > 0 && q.CA >= 0 && q.CB > 0 && q.CA + q.CB <= q.N, "wgrad_reduce_multi: job %d: bad column range", i);
+      r.kind = 2; r.S = q.S; r.N = q.N; r.CA = q.CA; r.CB = q.CB;
+      blocks += (q.CB + 31) / 32;
+    } else {
+      SEGK_FAIL(-2, "wgrad_reduce_multi: job %d: bad kind %d", i, q.kind);
+    }
+  }
+  if (lds > 48 * 1024) {
+    static bool attr_set[SEGK_MAX_DEVICES] = {};
+    const int dev = segk_device_index();
+    if (!attr_set[dev]) {
+      if (hipFuncSetAttribute((const void*)wgrad_reduce_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) !=
+          hipSuccess)
+        SEGK_FAIL(-3, "wgrad_reduce_multi: cannot raise dynamic LDS limit");
+      attr_set[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), lds, st, p);
+  SEGK_CHECK_LAUNCH("wgrad_reduce_multi");
   return 0;
 }
 

@@ -466,20 +466,25 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
       // reads" (s_waitcnt lgkmcnt(N)) names exactly what has arrived.
       const int ua = cur * BUF + wu * (NU * BLKP) + xa * BLKP + coff;
       const int va = cur * BUF + UB + wv * (NV * BLKP) + xa * BLKP + coff;
+      // the first MFMAs (ky = 0 of dz row 0) need dz row 0 and patch row 0 only: those 8 reads go first, patch rows 1 and 2
+      // (12 reads) land under them -- the row loop's first wait leaves 14 reads in flight instead of draining all 20
       s16x8 fv[3][3], fu[2];
+      frag_rd(fu[0], ua, std::integral_constant<int, 0>{});
       static_for<0, 9>([&](auto IC) {
         constexpr int y = decltype(IC)::value / 3, kx = decltype(IC)::value % 3;
         frag_rd(fv[y][kx], va, std::integral_constant<int, (y * 18 + kx) * BLKP>{});
       });
-      frag_rd(fu[0], ua, std::integral_constant<int, 0>{});
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (PRO) fu[0] = transform(fu[0], rows_ok > 0 ? xmask : 0u);
+      if (PRO) {
+        asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");     // dz row 0 (the oldest two of 20 reads; the field holds <= 15)
+        __builtin_amdgcn_sched_barrier(0);
+        fu[0] = transform(fu[0], rows_ok > 0 ? xmask : 0u);
+      }
       static_for<0, R>([&](auto RC) {
         constexpr int r = decltype(RC)::value;
         if constexpr (r + 1 < R) frag_rd(fu[(r + 1) & 1], ua, std::integral_constant<int, (r + 1) * 16 * BLKP>{});
-        // dz row r and patch row r are in registers: younger are patch row r+2 (6 reads, r > 0) and dz row r+1 (2)
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((r == 0 ? 0 : 6) + (r + 1 < R ? 2 : 0)) : "memory");
+        // dz row r and patch row r are in registers: younger are patch row r+2 (6 reads; at r = 0 patch rows 1 and 2: 12) and
+        // dz row r+1 (2)
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((r == 0 ? 12 : 6) + (r + 1 < R ? 2 : 0)) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 fur = __builtin_bit_cast(bf16x8, fu[r & 1]);
 #pragma unroll

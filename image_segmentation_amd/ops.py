@@ -523,6 +523,39 @@ def wgrad_to_param(slabs, S, shape, N, CA, CB, taps, dev, param=None):
     return grad
 
 
+class ReduceBatch:
+    """The fixed-order reductions that end a block's backward -- weight-gradient slabs -> reference-layout gradients, and the
+    ConvTranspose bias gradient from the concat data-gradient's channel sums -- collected and run by ONE launch per four
+    jobs (segk_wgrad_reduce_multi) instead of one launch each (and a stock torch.sum for the bias gradient).  The buffers
+    handed out by the add_* methods hold their values once flush() has been called."""
+
+    def __init__(self, dev):
+        self.dev, self.jobs, self.keep, self.nbytes = dev, [], [], 0.0
+
+    def add_weight(self, slabs, S, shape, N, CA, CB, taps, param=None):
+        grad = _grad_buffer(param, shape, self.dev)
+        self.jobs.append(_lib.ReduceJob(slabs.data_ptr(), grad.data_ptr(), 0, S, N, CA, CB, pad32(N), pad32(CA),
+                                        pad32(CB) if CB else 0, taps, 0))
+        self.keep.append(slabs)
+        self.nbytes += 4.0 * (S + 1) * grad.numel()
+        return grad
+
+    def add_colsum(self, part, rows, ntot, col0, ncols):
+        out = _f32(ncols, self.dev)
+        self.jobs.append(_lib.ReduceJob(part.data_ptr(), out.data_ptr(), 1, rows, ntot, col0, ncols, 0, 0, 0, 0, 0))
+        self.keep.append(part)
+        self.nbytes += 8.0 * rows * ncols
+        return out
+
+    def flush(self):
+        for i in range(0, len(self.jobs), 4):
+            chunk = self.jobs[i:i + 4]
+            arr = (_lib.ReduceJob * len(chunk))(*chunk)
+            with _span("wgrad_reduce", 0.0, self.nbytes * len(chunk) / len(self.jobs)):
+                _lib.call("segk_wgrad_reduce_multi", arr, len(chunk), _stream())
+        self.jobs, self.keep, self.nbytes = [], [], 0.0
+
+
 def bn_finalize(stats, tiles, C, count, conv_bias, bn_w, bn_b, rmean, rvar, momentum, eps, training, dev):
     Cp = pad32(C)
     scale, shift = _f32(Cp, dev), _f32(Cp, dev)
@@ -670,7 +703,7 @@ def _convt_fwd(mod, x_t, px, w, b, B, H, W, Cin, Cout, dtype, dev, both=False):
     return out
 
 
-def _convt_bwd(mod, x_t, w, pd, B, H, W, Cin, Cout, dtype, dev, need_dx, has_bias, chan_sum=None):
+def _convt_bwd(mod, x_t, w, pd, B, H, W, Cin, Cout, dtype, dev, need_dx, has_bias, chan_sum=None, batch=None):
     """Backward of _convt_fwd given the pointer of dout [B,2H,2W,Coutp] -> (dx act view or None, dw, db).
     chan_sum: per-channel sum of dout when the kernel that wrote dout already produced it (the bias gradient)."""
     Cinp, Coutp = pad32(Cin), pad32(Cout)
@@ -684,7 +717,10 @@ def _convt_bwd(mod, x_t, w, pd, B, H, W, Cin, Cout, dtype, dev, need_dx, has_bia
                       _stream())
         dx = act_view(dxb, Cin)
     slabs, S = wgrad(px, Cinp, pd, Coutp, 0, 0, B, H, W, 2, dtype, dev, alg=(Cin, Cout))
-    dw = wgrad_to_param(slabs, S, w.shape, Cin, Cout, 0, 4, dev, param=w)
+    if batch is not None:
+        dw = batch.add_weight(slabs, S, w.shape, Cin, Cout, 0, 4, param=w)
+    else:
+        dw = wgrad_to_param(slabs, S, w.shape, Cin, Cout, 0, 4, dev, param=w)
     db = None
     if has_bias:
         db = chan_sum if chan_sum is not None else channel_sum(pd, B * 4 * H * W, Cout, dtype, dev)
@@ -988,7 +1024,8 @@ class DoubleConvFn(torch.autograd.Function):
         else:
             slabs, S = wgrad(dz2.data_ptr(), Coutp, z1.data_ptr(), Coutp, 0, 0, B, H, W, 0, dtype, dev, scale=sc1,
                              shift=sh1, alg=(Cout, Cout))
-        dw2 = wgrad_to_param(slabs, S, w2.shape, Cout, Cout, 0, 9, dev, param=w2)
+        rb = ReduceBatch(dev)        # the block's slab reductions (and the ConvTranspose bias sum) run as one launch at the end
+        dw2 = rb.add_weight(slabs, S, w2.shape, Cout, Cout, 0, 9, param=w2)
         del slabs, dz2
 
         # ---- first conv (dz1 overwrites da1 in place: da1 is private to this function)
@@ -1013,18 +1050,17 @@ class DoubleConvFn(torch.autograd.Function):
             dxa = act_view(dxa_buf, CA)
             dxb = act_view(dxb_buf, CB) if CB else None
             if has_up:
-                part = std[:tiles_d * (CAp + CBp) * 2].view(tiles_d, CAp + CBp, 2)
-                chan_sum = part[:, CAp:CAp + CB, 0].sum(dim=0)
+                chan_sum = rb.add_colsum(std, tiles_d, CAp + CBp, CAp, CB)
         if ctx.stem_raw:        # the stem: im2col gather from the NCHW fp32 batch, slabs in OIHW column order (k = ci*9 + tap)
             S = _lib.query("segk_stem3x3_wgrad_slabs", B, H, W, CA, Cout, _DT[dtype])
             slabs = _f32(S * 64 * 32, dev)
             with _span("wgrad3x3", 2.0 * P * 9 * CA * Cout, P * (Cout * _es(dtype) + 4 * CA) + 4.0 * 9 * CA * Cout):
                 _lib.call("segk_stem3x3_wgrad", xa_t.data_ptr(), dz1.data_ptr(), slabs.data_ptr(), B, H, W, CA, Cout,
                           _DT[dtype], _stream())
-            dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, 9 * CA, 0, 1, dev, param=w1)
+            dw1 = rb.add_weight(slabs, S, w1.shape, Cout, 9 * CA, 0, 1, param=w1)
         else:
             slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev, alg=(Cout, CA + CB))
-            dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev, param=w1)
+            dw1 = rb.add_weight(slabs, S, w1.shape, Cout, CA, CB, 9, param=w1)
         del slabs
         # conv biases ahead of a batch-statistics BatchNorm have an identically zero gradient; ahead of a frozen one the
         # bias is part of the affine map: d(bias) = sum(dz) = scale * sum(g)
@@ -1039,8 +1075,10 @@ class DoubleConvFn(torch.autograd.Function):
         if has_up:
             Bu, Hu, Wu, Cin_u, Cout_u = ctx.up_dims
             d_up_x, d_up_w, d_up_b = _convt_bwd(cfg.up_mod, up_t, up_w, dxb_buf.data_ptr(), Bu, Hu, Wu, Cin_u, Cout_u, dtype,
-                                                dev, need[11], cfg.up_mod.upsample.bias is not None, chan_sum=chan_sum)
+                                                dev, need[11], cfg.up_mod.upsample.bias is not None, chan_sum=chan_sum,
+                                                batch=rb)
             dxb = None                   # xb was internal
+        rb.flush()
         return (None, dxa, dxb, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, d_up_x, d_up_w, d_up_b, d_head_w, d_head_b)
 
 
@@ -1294,12 +1332,13 @@ class SegLossFn(torch.autograd.Function):
         ign = -1 if ignore_index is None else int(ignore_index)
         part = _f32(_lib.query("segk_loss_part_floats", N * H * W), dev)
         state = _f32(_lib.query("segk_loss_state_floats"), dev)
+        out = _f32(1, dev)          # the returned loss lives in a buffer of its own (no copy kernel, no view of saved state)
         with _span("loss_fwd", 0.0, N * H * W * (4.0 * C + 8)):
             _lib.call("segk_loss_fwd", lg.data_ptr(), tg.data_ptr(), _p(cw), N, C, H * W, ign, float(smooth),
-                      float(dice_weight), float(ce_weight), part.data_ptr(), state.data_ptr(), _stream())
+                      float(dice_weight), float(ce_weight), part.data_ptr(), state.data_ptr(), out.data_ptr(), _stream())
         ctx.cfg = (N, C, H, W, ign, float(dice_weight), float(ce_weight))
         ctx.save_for_backward(lg, tg, cw, state)
-        return state[0].clone()
+        return out.view(())
 
     @staticmethod
     def backward(ctx, gout):
@@ -1343,13 +1382,14 @@ class ProbLossFn(torch.autograd.Function):
         ign = -1 if ignore_index is None else int(ignore_index)
         part = _f32(_lib.query("segk_loss_part_floats", N * H * W), dev)
         state = _f32(_lib.query("segk_loss_state_floats"), dev)
+        out = _f32(1, dev)
         with _span("loss_fwd", 0.0, N * H * W * (4.0 * C + 8)):
             _lib.call("segk_prob_loss_fwd", pr.data_ptr(), tg.data_ptr(), _p(cw), N, C, H * W, ign, float(smooth),
                       float(dice_weight), float(nll_weight), int(nll_log), float(eps), part.data_ptr(), state.data_ptr(),
-                      _stream())
+                      out.data_ptr(), _stream())
         ctx.cfg = (N, C, H, W, ign, float(dice_weight), float(nll_weight), int(nll_log), float(eps))
         ctx.save_for_backward(pr, tg, cw, state)
-        return state[0].clone()
+        return out.view(())
 
     @staticmethod
     def backward(ctx, gout):

@@ -33,7 +33,7 @@ typedef void* segk_stream_t; /* hipStream_t */
 /* ABI version and the number of entry points this header declares: segk_version() / segk_entry_count() of a library
  * must equal them (image_segmentation_amd/_lib.py refuses a library whose values differ from the table it binds) */
 #define SEGK_ABI_VERSION 300
-#define SEGK_ENTRY_COUNT 67
+#define SEGK_ENTRY_COUNT 68
 int segk_version(void);
 int segk_entry_count(void);
 /* first 16 hex digits of the sha256 over the sources this library was built from (image_segmentation_amd/build.py:
@@ -134,6 +134,18 @@ int segk_wgrad(const void* dz, const void* srcA, const void* srcB, const float* 
                                                   LDS-DMA path); NULL selects the register-staged kernel */
 int segk_wgrad_reduce(const float* slabs, int S, float* grad, int N, int CA, int CB, int Np, int CAp, int CBp,
                       int taps, segk_stream_t s);
+/* Up to four such reductions in ONE launch -- the two weight gradients of a DoubleConv block (unet.py:16,19), the
+ * ConvTranspose2d weight gradient of the Up block around it (unet.py:59) and that layer's bias gradient: jobs is a HOST
+ * array (read during the call).  kind 0: segk_wgrad_reduce(src = slabs, S, dst = grad, N, CA, CB, Np, CAp, CBp, taps);
+ * kind 1: column sums dst[c] = sum over rows r < S of src[(r * N + CA + c) * 2], c < CB (N = channels per row of the
+ * [rows][N][2] BatchNorm-style partials segk_conv3x3 writes: the bias gradient of the ConvTranspose whose output is the
+ * second concat operand is the channel sum of the concat data gradient).  Results equal the single launches bit for bit. */
+typedef struct segk_reduce_job {
+  const float* src;
+  float* dst;
+  int kind, S, N, CA, CB, Np, CAp, CBp, taps, pad_;
+} segk_reduce_job;
+int segk_wgrad_reduce_multi(const segk_reduce_job* jobs, int n, segk_stream_t s);
 
 /* ---- BatchNorm2d + ReLU (unet.py:17-18,20-21; clipunet.py:88-89,91-92) ---------------------------
  * training: stats partials -> scale = gamma*rstd, shift = beta - mean*scale, batch mean/rstd saved for
@@ -269,7 +281,9 @@ int segk_loss_part_floats(long P);
 int segk_loss_state_floats(void);
 int segk_loss_fwd(const float* logits, const int64_t* labels, const float* class_weights, int N, int C, long HW,
                   int ignore_index, float smooth, float dice_weight, float ce_weight, float* part, float* state,
-                  segk_stream_t s);
+                  float* loss_out, segk_stream_t s);   /* loss_out (may be NULL): one float, a copy of state[0] (the value the
+                                                          nn.Module returns, in a buffer of its own); the block of the
+                                                          launch that finishes last turns the partials into the state */
 int segk_loss_bwd(const float* logits, const int64_t* labels, const float* class_weights, const float* state,
                   const float* grad_out, int N, int C, long HW, int ignore_index, float dice_weight, float ce_weight,
                   float* dlogits, segk_stream_t s);
@@ -287,7 +301,7 @@ int segk_prompt_mix_bwd(const float* clip_logits, const float* mask_logit, const
  * part/state sized like segk_loss_fwd's. */
 int segk_prob_loss_fwd(const float* probs, const int64_t* labels, const float* class_weights, int N, int C, long HW,
                        int ignore_index, float smooth, float dice_weight, float nll_weight, int nll_log, float eps,
-                       float* part, float* state, segk_stream_t s);
+                       float* part, float* state, float* loss_out, segk_stream_t s);
 int segk_prob_loss_bwd(const float* probs, const int64_t* labels, const float* class_weights, const float* state,
                        const float* grad_out, int N, int C, long HW, int ignore_index, float dice_weight,
                        float nll_weight, int nll_log, float eps, float* dprobs, segk_stream_t s);

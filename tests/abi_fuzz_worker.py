@@ -17,6 +17,7 @@ lib.segk_last_error.restype = C.c_char_p
 QUERIES = {"segk_version", "segk_entry_count", "segk_stem3x3_wgrad_slabs", "segk_stem3x3_rows", "segk_pack_convt_chunk", "segk_conv_tiles", "segk_bn_stats_floats", "segk_conv_writes_act_q", "segk_wgrad_tiles", "segk_wgrad_split",
            "segk_bn_bwd_blocks", "segk_maxpool_bwd_stat_blocks", "segk_head_part_floats", "segk_head_bwd_blocks",
            "segk_loss_part_floats", "segk_loss_state_floats"}
+SPECIAL = {"segk_wgrad_reduce_multi"}           # takes a host array of structs: driven by its own patterns below
 
 
 def args_for(argtypes, ints, ptr):
@@ -56,6 +57,21 @@ for name, (res, argtypes) in sorted(_lib.SIGNATURES.items()):
     fn.argtypes = argtypes
     if res is C.c_char_p:
         fn()
+        continue
+    if name in SPECIAL:                          # host-read job array: NULL, a bad count, and jobs with NULL / bad fields
+        jobs = (_lib.ReduceJob * 4)()
+        cases = [(None, 1), (jobs, 0), (jobs, 5), (jobs, 2)]
+        jobs2 = (_lib.ReduceJob * 1)(_lib.ReduceJob(256, 256, 7, 1, 1, 1, 0, 32, 32, 0, 1, 0))      # unknown kind
+        jobs3 = (_lib.ReduceJob * 1)(_lib.ReduceJob(256, 256, 0, 0, -1, 33, 0, 32, 32, 0, 9, 0))    # nonsense sizes
+        jobs4 = (_lib.ReduceJob * 1)(_lib.ReduceJob(256, 256, 1, 4, 64, 60, 8, 0, 0, 0, 0, 0))      # column range past the row
+        cases += [(jobs2, 1), (jobs3, 1), (jobs4, 1)]
+        for arr, n in cases:
+            print(f"call {name} n={n}", file=sys.stderr, flush=True)
+            rc = fn(arr, n, None)
+            calls += 1
+            msg = lib.segk_last_error() or b""
+            if rc != -2 or not msg:
+                bad.append({"fn": name, "ints": [n], "ptr": 0, "rc": rc, "msg": msg.decode(errors="replace")[:120]})
         continue
     if name in QUERIES:
         for ints in ([0], [-1], [1], [7, 3], [1 << 20], [2, 32, 32, 64, 64, 1], [1, 1, 1, 1, 1, 0]):

@@ -605,3 +605,35 @@ def test_biased_conv_on_rs_shape_falls_through_to_ws_and_refuses_statistics(ops)
     assert float(st.abs().sum()) == 0.0                                           # nothing was launched
 
 
+
+
+def test_wgrad_reduce_multi_equals_single_launches(ops):
+    """segk_wgrad_reduce_multi: the slab reductions of a block's backward (row form S <= 16, slab-parallel form S > 16, a
+    two-source 3x3 weight, a 4-tap ConvTranspose weight) and the ConvTranspose bias gradient as column sums of BatchNorm-style
+    partial rows, four jobs in ONE launch: bit-identical to the single-job launches; the column sums equal torch's."""
+    from image_segmentation_amd import _lib
+    s = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+
+    def weight_job(S, N, CA, CB, taps):
+        Np, CAp, CBp = ops.pad32(N), ops.pad32(CA), (ops.pad32(CB) if CB else 0)
+        slabs = torch.randn((S, Np, taps, CAp + CBp), device="cuda", generator=gen)
+        single = torch.empty((N, CA + CB, taps), device="cuda")
+        _lib.call("segk_wgrad_reduce", slabs.data_ptr(), S, single.data_ptr(), N, CA, CB, Np, CAp, CBp, taps, s)
+        multi = torch.full_like(single, 7.0)
+        return slabs, single, multi, _lib.ReduceJob(slabs.data_ptr(), multi.data_ptr(), 0, S, N, CA, CB, Np, CAp, CBp, taps, 0)
+    jobs = [weight_job(8, 128, 128, 0, 9), weight_job(64, 64, 40, 72, 9), weight_job(256, 64, 64, 0, 4)]
+    rows, ntot, col0, ncols = 300, 192, 64, 100
+    part = torch.randn((rows, ntot, 2), device="cuda", generator=gen)
+    colsum = torch.empty((ncols,), device="cuda")
+    arr = (_lib.ReduceJob * 4)(jobs[0][3], jobs[1][3], jobs[2][3],
+                               _lib.ReduceJob(part.data_ptr(), colsum.data_ptr(), 1, rows, ntot, col0, ncols, 0, 0, 0, 0, 0))
+    for _ in range(2):
+        _lib.call("segk_wgrad_reduce_multi", arr, 4, s)
+    torch.cuda.synchronize()
+    for slabs, single, multi, _ in jobs:
+        assert torch.equal(single, multi)
+    want = part[:, col0:col0 + ncols, 0].double().sum(0)
+    assert (colsum.double() - want).abs().max().item() < 1e-4
+    with pytest.raises(RuntimeError, match="1..4 jobs"):
+        _lib.call("segk_wgrad_reduce_multi", arr, 5, s)
