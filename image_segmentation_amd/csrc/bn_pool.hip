@@ -131,22 +131,13 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_small_kernel(const flo
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   double a1[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, a2[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  // the walk is latency-bound (the partials were just written by other CUs): four passes of eight rows are loaded
-  // together -- 32 rows in flight per lane, i.e. all of a 1024-row buffer at once -- and added in the order of the one-pass
-  // loop (accumulator u takes rows ry + 256 k + 32 u in ascending k): bit-identical sums
-  for (int m = ry; m < MT; m += 1024) {
-    float2 v[4][8];
+  for (int m = ry; m < MT; m += 256) {
+    float2 v[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int u = 0; u < 8; ++u)
+      v[u] = (m + 32 * u < MT) ? ((const float2*)part)[(size_t)(m + 32 * u) * C + c] : make_float2(0.f, 0.f);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int row = m + 256 * k + 32 * u;
-        v[k][u] = (row < MT) ? ((const float2*)part)[(size_t)row * C + c] : make_float2(0.f, 0.f);
-      }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { a1[u] += (double)v[k][u].x; a2[u] += (double)v[k][u].y; }
+    for (int u = 0; u < 8; ++u) { a1[u] += (double)v[u].x; a2[u] += (double)v[u].y; }
   }
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -285,21 +276,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   if (c < C) {
     // four independent rows in flight per pass (latency-bound walk); fixed order of additions: bit-stable
     double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
-    // four passes of four rows loaded together (16 rows in flight per lane: a 512-row buffer in one round trip), added in
-    // the order of the one-pass loop: bit-identical sums
-    for (int m = ry; m < NB; m += 512) {
-      float2 v[4][4];
+    for (int m = ry; m < NB; m += 128) {
+      float2 v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int u = 0; u < 4; ++u)
+        v[u] = (m + 32 * u < NB) ? ((const float2*)part)[(size_t)(m + 32 * u) * C + c] : make_float2(0.f, 0.f);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int row = m + 128 * k + 32 * u;
-          v[k][u] = (row < NB) ? ((const float2*)part)[(size_t)row * C + c] : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { a1[u] += (double)v[k][u].x; a2[u] += (double)v[k][u].y; }
+      for (int u = 0; u < 4; ++u) { a1[u] += (double)v[u].x; a2[u] += (double)v[u].y; }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { s1 += a1[u]; s2 += a2[u]; }

@@ -277,20 +277,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
 }
 
 // Column sums of BatchNorm-style partial rows: out[c] = sum over rows of part[row][col0 + c][0] (stride 2 floats per
-// channel): the ConvTranspose bias gradient taken from the concat data-gradient's per-tile channel sums.  One block per 32
-// channels, 8 row lanes, fp64, fixed order.
+// channel): the ConvTranspose bias gradient taken from the concat data-gradient's per-tile channel sums.  One block per 8
+// channels: 32 row lanes with eight rows in flight each (the walk is latency-bound), fp64, fixed order.
 __device__ __forceinline__ void colsum_block(const float* __restrict__ part, int rows, int Ctot, int col0, int C,
-                                             float* __restrict__ out, int cb, double (&sh)[8][32]) {
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = cb * 32 + cx;
-  double s = 0.0;
+                                             float* __restrict__ out, int cb, double (&sh)[32][8]) {
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = cb * 8 + cx;
+  double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (c < C)
-    for (int r = ry; r < rows; r += 8) s += (double)part[((size_t)r * Ctot + col0 + c) * 2];
+    for (int r = ry; r < rows; r += 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (r + 32 * u < rows) ? part[((size_t)(r + 32 * u) * Ctot + col0 + c) * 2] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += (double)v[u];
+    }
+  double s = 0.0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s += a8[u];
   sh[ry][cx] = s;
   __syncthreads();
   if (ry != 0 || c >= C) return;
   s = 0.0;
-  for (int r = 0; r < 8; ++r) s += sh[r][cx];
+  for (int r = 0; r < 32; ++r) s += sh[r][cx];
   out[c] = (float)s;
 }
 
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const ReduceJob
   } else if (jb.kind == 1) {
     wgrad_reduce_wide(jb.src, jb.S, jb.dst, local / jb.ny, local % jb.ny, jb.CA, jb.CB, jb.Np, jb.CAp, jb.CBp, jb.taps, red);
   } else {
-    colsum_block(jb.src, jb.S, jb.N, jb.CA, jb.CB, jb.dst, local, *(double(*)[8][32])red);
+    colsum_block(jb.src, jb.S, jb.N, jb.CA, jb.CB, jb.dst, local, *(double(*)[32][8])red);
   }
 }
 
@@ -451,7 +460,7 @@ int segk_wgrad_reduce_multi_impl(const segk_reduce_job* jobs, int n, hipStream_t
     } else if (q.kind == 1) { // column sums of partial rows
       SEGK_REQUIRE(q.S > 0 && q.N > 0 && q.CA >= 0 && q.CB > 0 && q.CA + q.CB <= q.N, "wgrad_reduce_multi: job %d: bad column range", i);
       r.kind = 2; r.S = q.S; r.N = q.N; r.CA = q.CA; r.CB = q.CB;
-      blocks += (q.CB + 31) / 32;
+      blocks += (q.CB + 7) / 8;
     } else {
       SEGK_FAIL(-2, "wgrad_reduce_multi: job %d: bad kind %d", i, q.kind);
     }

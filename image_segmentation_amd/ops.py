@@ -524,10 +524,11 @@ def wgrad_to_param(slabs, S, shape, N, CA, CB, taps, dev, param=None):
 
 
 class ReduceBatch:
-    """The fixed-order reductions that end a block's backward -- weight-gradient slabs -> reference-layout gradients, and the
-    ConvTranspose bias gradient from the concat data-gradient's channel sums -- collected and run by ONE launch per four
-    jobs (segk_wgrad_reduce_multi) instead of one launch each (and a stock torch.sum for the bias gradient).  The buffers
-    handed out by the add_* methods hold their values once flush() has been called."""
+    """Fixed-order reductions collected and run by ONE launch per four jobs (segk_wgrad_reduce_multi): the ConvTranspose
+    weight-gradient slabs of an Up block together with that layer's bias gradient (column sums of the concat
+    data-gradient's per-tile channel sums: no stock torch.sum).  The buffers handed out by the add_* methods hold their
+    values once flush() has been called.  Only reductions whose inputs were produced just before belong in one batch: a
+    slab buffer that waits for a later launch drops out of the Infinity Cache (measured: slower than separate launches)."""
 
     def __init__(self, dev):
         self.dev, self.jobs, self.keep, self.nbytes = dev, [], [], 0.0
@@ -1024,8 +1025,10 @@ class DoubleConvFn(torch.autograd.Function):
         else:
             slabs, S = wgrad(dz2.data_ptr(), Coutp, z1.data_ptr(), Coutp, 0, 0, B, H, W, 0, dtype, dev, scale=sc1,
                              shift=sh1, alg=(Cout, Cout))
-        rb = ReduceBatch(dev)        # the block's slab reductions (and the ConvTranspose bias sum) run as one launch at the end
-        dw2 = rb.add_weight(slabs, S, w2.shape, Cout, Cout, 0, 9, param=w2)
+        # (each slab reduction runs right behind its weight-gradient kernel, while the slabs still sit in the Infinity
+        # Cache: deferring a block's reductions into one launch at the end read them back from HBM and was slower)
+        dw2 = wgrad_to_param(slabs, S, w2.shape, Cout, Cout, 0, 9, dev, param=w2)
+        rb = ReduceBatch(dev)        # the ConvTranspose weight gradient and its bias gradient's column sums: one launch
         del slabs, dz2
 
         # ---- first conv (dz1 overwrites da1 in place: da1 is private to this function)
@@ -1057,10 +1060,10 @@ class DoubleConvFn(torch.autograd.Function):
             with _span("wgrad3x3", 2.0 * P * 9 * CA * Cout, P * (Cout * _es(dtype) + 4 * CA) + 4.0 * 9 * CA * Cout):
                 _lib.call("segk_stem3x3_wgrad", xa_t.data_ptr(), dz1.data_ptr(), slabs.data_ptr(), B, H, W, CA, Cout,
                           _DT[dtype], _stream())
-            dw1 = rb.add_weight(slabs, S, w1.shape, Cout, 9 * CA, 0, 1, param=w1)
+            dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, 9 * CA, 0, 1, dev, param=w1)
         else:
             slabs, S = wgrad(dz1.data_ptr(), Coutp, pA, CAp, pB, CBp, B, H, W, 0, dtype, dev, alg=(Cout, CA + CB))
-            dw1 = rb.add_weight(slabs, S, w1.shape, Cout, CA, CB, 9, param=w1)
+            dw1 = wgrad_to_param(slabs, S, w1.shape, Cout, CA, CB, 9, dev, param=w1)
         del slabs
         # conv biases ahead of a batch-statistics BatchNorm have an identically zero gradient; ahead of a frozen one the
         # bias is part of the affine map: d(bias) = sum(dz) = scale * sum(g)

@@ -5,6 +5,7 @@ syntax errors until the GPU passes have already been paid for; tests/test_tools.
     pmc_post.py traffic  <out_dir> <repo_root> [round_tag]   FETCH_SIZE / WRITE_SIZE passes  -> <out_dir>/pmc_traffic.json
     pmc_post.py mfma_lds <out_dir> <repo_root>               MFMA busy / LDS conflict passes -> <out_dir>/pmc_mfma_lds.json
     pmc_post.py summary  <out_dir>                           mean counter value per kernel   -> <out_dir>/summary.txt
+    pmc_post.py stats    <kernel_stats.csv> <steps>          per-step table of a rocprofv3 --stats summary
 """
 import collections
 import csv
@@ -124,6 +125,15 @@ def summary(out):
     print(open(f"{out}/summary.txt").read()[:6000])
 
 
+def stats(path, steps):
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps
+    print(f"kernel time per step {tot / 1e6:.3f} ms, launches per step {sum(int(r['Calls']) for r in rows) / steps:.1f}")
+    for r in rows[:50]:
+        print(f"{float(r['TotalDurationNs']) / steps / 1e3:9.1f} us/step {int(r['Calls']) / steps:6.2f} x "
+              f"{float(r['AverageNs']) / 1e3:8.1f} us  {short(r['Name'])[:100]}")
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
     if cmd == "traffic":
@@ -132,5 +142,7 @@ if __name__ == "__main__":
         mfma_lds(sys.argv[2], sys.argv[3])
     elif cmd == "summary":
         summary(sys.argv[2])
+    elif cmd == "stats":
+        stats(sys.argv[2], int(sys.argv[3]))
     else:
         sys.exit(f"unknown command {cmd}")
