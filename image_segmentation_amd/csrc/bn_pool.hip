@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 }
 
 // training mode, few partial rows (MT <= 1024: every layer but the 128-channel ones at 128x128 and above): one block of
-// 32 row lanes x 32 channels walks all rows itself, eight rows in flight per lane, and finishes -- no second stage at all
+// 32 row lanes x 32 channels walks all rows itself, sixteen rows in flight per lane, and finishes -- no second stage at all
 __global__ __launch_bounds__(1024) void bn_stats_finalize_small_kernel(const float* __restrict__ part, int MT, int C,
                                                                        int C_real, double count, const float* conv_bias,
                                                                        const float* gamma, const float* beta, float* rmean,
@@ -130,24 +130,31 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_small_kernel(const flo
   __shared__ double sh[32][32][2];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
-  double a1[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, a2[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int m = ry; m < MT; m += 256) {
-    float2 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      v[u] = (m + 32 * u < MT) ? ((const float2*)part)[(size_t)(m + 32 * u) * C + c] : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { a1[u] += (double)v[u].x; a2[u] += (double)v[u].y; }
-  }
+  // sixteen rows in flight per lane and ONE accumulator pair (the registers hold loads, not partial sums: 1024 threads leave
+  // 128 per lane): MT <= 512 is a single memory round trip.  Fixed order of additions: bit-stable
   double s1 = 0.0, s2 = 0.0;
+#pragma unroll 1
+  for (int m = ry; m < MT; m += 512) {
+    float2 v[16];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) { s1 += a1[u]; s2 += a2[u]; }     // fixed order: bit-stable
+    for (int u = 0; u < 16; ++u) {   // unconditional loads of a clamped row (a conditional load compiles to branch + wait)
+      const int r = m + 32 * u < MT ? m + 32 * u : MT - 1;
+      v[u] = ((const float2*)part)[(unsigned)r * (unsigned)C + (unsigned)c];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const bool ok = m + 32 * u < MT;
+      s1 += ok ? (double)v[u].x : 0.0;
+      s2 += ok ? (double)v[u].y : 0.0;
+    }
+  }
   sh[ry][cx][0] = s1;
   sh[ry][cx][1] = s2;
   __syncthreads();
   if (ry != 0) return;
   s1 = 0.0; s2 = 0.0;
-  for (int r = 0; r < 32; ++r) { s1 += sh[r][cx][0]; s2 += sh[r][cx][1]; }
+#pragma unroll 8
+  for (int r = 0; r < 32; ++r) { s1 += sh[r][cx][0]; s2 += sh[r][cx][1]; }   // (32 reads in flight would spill)
   if (c >= C_real) {  // padded channel: stays identically zero
     scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; rstd_out[c] = 0.f;
     return;
@@ -199,13 +206,18 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
   float sc[E::VEC], sh[E::VEC];
 #pragma unroll
   for (int j = 0; j < E::VEC; ++j) { sc[j] = scale[l.cv * E::VEC + j]; sh[j] = shift[l.cv * E::VEC + j]; }
-  for (long p = (long)blockIdx.x * rows + l.ry; p < P; p += (long)gridDim.x * rows) {
-    const size_t off = (size_t)p * C + l.cv * E::VEC;
+  auto one = [&](const uint4 raw, const size_t off) {
     float f[E::VEC];
-    unpack16<T>(*(const uint4*)(z + off), f);
+    unpack16<T>(raw, f);
 #pragma unroll
     for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
     *(uint4*)(y + off) = pack16<T>(f);
+  };
+  // one pixel per thread per pass: like the backward apply pass (see there) this read + write stream does not gain from
+  // more loads in flight per thread
+  for (long p = (long)blockIdx.x * rows + l.ry; p < P; p += (long)gridDim.x * rows) {
+    const size_t off = (size_t)p * C + (size_t)l.cv * E::VEC;
+    one(*(const uint4*)(z + off), off);
   }
 }
 
@@ -230,17 +242,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       const int c = l.cv * E::VEC + j;
       sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
     }
-    for (long p = (long)blockIdx.x * rows + l.ry; p < P; p += (long)gridDim.x * rows) {
-      const size_t off = (size_t)p * C + l.cv * E::VEC;
+    auto one = [&](const uint4 rz, const uint4 rd) {
       float fz[E::VEC], fd[E::VEC];
-      unpack16<T>(*(const uint4*)(z + off), fz);
-      unpack16<T>(*(const uint4*)(dy + off), fd);
+      unpack16<T>(rz, fz);
+      unpack16<T>(rd, fd);
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) {
         const float g = (fmaf(fz[j], sc[j], sh[j]) > 0.f) ? fd[j] : 0.f;
         sg[j] += g;
         sgx[j] = fmaf(g, (fz[j] - mu[j]) * rs[j], sgx[j]);
       }
+    };
+    // four pixels (eight loads) per thread in flight: the grid is only two blocks per CU (short finalize), and left to itself
+    // the compiler keeps one pixel in flight.  Pixels are consumed in the old order: bit-identical sums
+    const long step = (long)gridDim.x * rows;
+    const size_t cofs = (size_t)l.cv * E::VEC;
+    long p = (long)blockIdx.x * rows + l.ry;
+    for (; p + 3 * step < P; p += 4 * step) {
+      uint4 rz[4], rd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t off = (size_t)(p + u * step) * C + cofs;
+        rz[u] = *(const uint4*)(z + off);
+        rd[u] = *(const uint4*)(dy + off);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the loads back to two in flight)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(rz[u], rd[u]);
+    }
+    for (; p < P; p += step) {
+      const size_t off = (size_t)p * C + cofs;
+      one(*(const uint4*)(z + off), *(const uint4*)(dy + off));
     }
   }
   if (l.ry < rows) {
@@ -274,18 +306,22 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   const int c = blockIdx.x * 32 + cx;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    // four independent rows in flight per pass (latency-bound walk); fixed order of additions: bit-stable
-    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int m = ry; m < NB; m += 128) {
-      float2 v[4];
+    // sixteen rows in flight per lane, one accumulator pair: NB <= 512 (segk_bn_bwd_blocks) is ONE memory round trip.
+    // Fixed order of additions: bit-stable
+    for (int m = ry; m < NB; m += 512) {
+      float2 v[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        v[u] = (m + 32 * u < NB) ? ((const float2*)part)[(size_t)(m + 32 * u) * C + c] : make_float2(0.f, 0.f);
+      for (int u = 0; u < 16; ++u) {   // unconditional loads of a clamped row (a conditional load compiles to branch + wait)
+        const int r = m + 32 * u < NB ? m + 32 * u : NB - 1;
+        v[u] = ((const float2*)part)[(unsigned)r * (unsigned)C + (unsigned)c];
+      }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { a1[u] += (double)v[u].x; a2[u] += (double)v[u].y; }
+      for (int u = 0; u < 16; ++u) {
+        const bool ok = m + 32 * u < NB;
+        s1 += ok ? (double)v[u].x : 0.0;
+        s2 += ok ? (double)v[u].y : 0.0;
+      }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { s1 += a1[u]; s2 += a2[u]; }
   }
   sh[ry][cx][0] = s1;
   sh[ry][cx][1] = s2;
@@ -314,11 +350,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
     c1[j] = coef[2 * c]; c2[j] = coef[2 * c + 1];
   }
-  for (long p = (long)blockIdx.x * rows + l.ry; p < P; p += (long)gridDim.x * rows) {
-    const size_t off = (size_t)p * C + l.cv * E::VEC;
+  auto one = [&](const uint4 rz, const uint4 rd, const size_t off) {
     float fz[E::VEC], fd[E::VEC];
-    unpack16<T>(*(const uint4*)(z + off), fz);
-    unpack16<T>(*(const uint4*)(dy + off), fd);
+    unpack16<T>(rz, fz);
+    unpack16<T>(rd, fd);
 #pragma unroll
     for (int j = 0; j < E::VEC; ++j) {
       const float g = (fmaf(fz[j], sc[j], sh[j]) > 0.f) ? fd[j] : 0.f;
@@ -326,6 +361,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       fd[j] = sc[j] * (g - c1[j] - xh * c2[j]);
     }
     *(uint4*)(dz + off) = pack16<T>(fd);
+  };
+  // APF pixels (2 APF loads) per thread in flight, all issued before the first store (dz may be dy or z: in place allowed,
+  // a thread only ever reads the elements it writes).  Measured at B = 32 (reduce + finalize + apply, us, same box):
+  // APF 1 / 2 / 4 = 250 / 274 / 278 at 64 ch x 256^2, 122 / 125 / 132 at 128 x 128^2 -- a pass that WRITES as much as it reads
+  // streams best with one pixel per thread and the occupancy that leaves; the read-only reduce pass gains from four
+#ifndef SEGK_BN_APPLY_FLIGHT
+#define SEGK_BN_APPLY_FLIGHT 1
+#endif
+  constexpr int APF = SEGK_BN_APPLY_FLIGHT;
+  const long step = (long)gridDim.x * rows;
+  const size_t cofs = (size_t)l.cv * E::VEC;
+  long p = (long)blockIdx.x * rows + l.ry;
+  for (; p + (APF - 1) * step < P; p += APF * step) {
+    size_t o[APF];
+    uint4 rz[APF], rd[APF];
+#pragma unroll
+    for (int u = 0; u < APF; ++u) {
+      o[u] = (size_t)(p + u * step) * C + cofs;
+      rz[u] = *(const uint4*)(z + o[u]);
+      rd[u] = *(const uint4*)(dy + o[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < APF; ++u) one(rz[u], rd[u], o[u]);
+  }
+  for (; p < P; p += step) {
+    const size_t o0 = (size_t)p * C + cofs;
+    one(*(const uint4*)(z + o0), *(const uint4*)(dy + o0), o0);
   }
 }
 
@@ -349,13 +411,23 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __rest
     float sc[E::VEC], sh[E::VEC], mx[E::VEC];
 #pragma unroll
     for (int j = 0; j < E::VEC; ++j) { sc[j] = scale[cv * E::VEC + j]; sh[j] = shift[cv * E::VEC + j]; mx[j] = 0.f; }
+    // the four loads of the window are issued together, unconditionally, from coordinates clamped into the image (a load
+    // under a per-lane condition compiles to branch + load + wait: four serial round trips per window)
+    size_t offs[4];
+    uint4 raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
+      offs[k] = (((size_t)(b * H + (yy < H ? yy : H - 1))) * W + (xx < W ? xx : W - 1)) * C + cv * E::VEC;
+      raw[k] = *(const uint4*)(z + offs[k]);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
       if (yy >= H || xx >= W) continue;
-      const size_t off = (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC;
+      const size_t off = offs[k];
       float f[E::VEC];
-      unpack16<T>(*(const uint4*)(z + off), f);
+      unpack16<T>(raw[k], f);
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
       const uint4 pk = pack16<T>(f);
@@ -439,33 +511,42 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     const int yo = (int)(p % Hc);
     const int b = (int)(p / Hc);
     const bool inwin = (yo < Ho) && (xo < Wo);
-    float g[E::VEC];
-    float v[4][E::VEC];
-    if (inwin) unpack16<T>(*(const uint4*)(dy + (((size_t)(b * Ho + yo)) * Wo + xo) * C + cv * E::VEC), g);
+    // every load of the window is issued before any is used, unconditionally, from coordinates clamped into the image (a
+    // load under a per-lane condition compiles to branch + load + wait: nine serial memory round trips per window)
+    const int yoc = yo < Ho ? yo : Ho - 1, xoc = xo < Wo ? xo : Wo - 1;
+    const uint4 rg = *(const uint4*)(dy + (((size_t)(b * Ho + yoc)) * Wo + xoc) * C + cv * E::VEC);
+    uint4 rv[4], ro[4];
+    size_t off[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
-      if (inwin || (STAT && yy < H && xx < W))
-        unpack16<T>(*(const uint4*)(x + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC), v[k]);
+      off[k] = (((size_t)(b * H + (yy < H ? yy : H - 1))) * W + (xx < W ? xx : W - 1)) * C + cv * E::VEC;
+      rv[k] = *(const uint4*)(x + off[k]);
     }
+    if (accumulate) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ro[k] = *(const uint4*)(dx + off[k]);
+    }
+    float g[E::VEC];
+    float v[4][E::VEC];
+    unpack16<T>(rg, g);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) unpack16<T>(rv[k], v[k]);
     int sel[E::VEC];
 #pragma unroll
     for (int j = 0; j < E::VEC; ++j) {
       sel[j] = 0;
-      if (inwin) {
-        float m = v[0][j];
+      float m = v[0][j];
 #pragma unroll
-        for (int k = 1; k < 4; ++k)
-          if (v[k][j] > m) { m = v[k][j]; sel[j] = k; }  // strict '>' keeps the FIRST maximum
-      }
+      for (int k = 1; k < 4; ++k)
+        if (v[k][j] > m) { m = v[k][j]; sel[j] = k; }  // strict '>' keeps the FIRST maximum
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
       if (yy >= H || xx >= W) continue;
-      T* dst = dx + (((size_t)(b * H + yy)) * W + xx) * C + cv * E::VEC;
       float o[E::VEC];
-      if (accumulate) unpack16<T>(*(const uint4*)dst, o);
+      if (accumulate) unpack16<T>(ro[k], o);
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) {
         const float r = (inwin && sel[j] == k) ? g[j] : 0.f;
@@ -476,7 +557,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
           sgx[j] = fmaf(gg, fmaf(v[k][j], xa[j], xb[j]), sgx[j]);
         }
       }
-      *(uint4*)dst = pack16<T>(o);
+      *(uint4*)(dx + off[k]) = pack16<T>(o);
     }
   }
   if (STAT) {

@@ -50,11 +50,23 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
         }
         __syncthreads();
       }
-      for (int q = tid; q < HT * VPR; q += 256) {
-        const int px = q / VPR, v = q - px * VPR;
+      // all of the thread's vectors of this pass are fetched before the first is used, unconditionally, from a pixel /
+      // channel index clamped into the tensor (left as a loop of conditional loads the compiler keeps ONE in flight)
+      constexpr int NQ = HT * VPR / 256;
+      uint4 raw[NQ];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int q = tid + 256 * u, px = q / VPR, v = q - px * VPR;
+        const long pp = p0 + px < P ? p0 + px : P - 1;
+        const int cc = c0 + v * E::VEC < Cp ? c0 + v * E::VEC : 0;
+        raw[u] = *(const uint4*)(y + (size_t)pp * Cp + cc);
+      }
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int q = tid + 256 * u, px = q / VPR, v = q - px * VPR;
         uint4 d = make_uint4(0, 0, 0, 0);
         if (p0 + px < P && c0 + v * E::VEC < Cp) {
-          d = *(const uint4*)(y + (size_t)(p0 + px) * Cp + c0 + v * E::VEC);
+          d = raw[u];
           if (zsc != nullptr) {
             float f[E::VEC];
             unpack16<T>(d, f);
@@ -176,7 +188,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     auto load_dl = [&](long p, float (&dl)[NC]) {
       const long b = p / HW, r = p - b * HW;
 #pragma unroll
-      for (int k = 0; k < NC; ++k) dl[k] = (k < ncls) ? dlog[(b * ncls + k) * HW + r] : 0.f;
+      for (int k = 0; k < NC; ++k) {   // unconditional loads (class index clamped), selected afterwards
+        const float v = dlog[(b * ncls + (k < ncls ? k : ncls - 1)) * HW + r];
+        dl[k] = (k < ncls) ? v : 0.f;
+      }
     };
     // two pixels per iteration: both loads are in flight before either is used (the loop is latency-bound otherwise)
     const long step = (long)gridDim.x * rows;
@@ -280,34 +295,34 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 
 // state: [0]=loss [1]=ce [2]=dice(-mean dc) [3]=ce_den, [4..4+MAXC) dc, [.. ) den_raw(Sp+Sg+smooth), [..) a_k
 constexpr int LS = 4 + 3 * MAXC;
-// runs in ONE block of 256 threads: the block of loss_fwd_kernel that finished last (ticket.hpp)
+// runs in ONE block of LT threads: the block of loss_fwd_kernel that finished last (ticket.hpp).  NB <= LROWS partial rows:
+// every thread takes one column of LROWS / (LT / 32) rows, all loads in flight at once (ONE memory round trip: the rows were
+// written by other XCDs and come from memory); additions in one fixed order: bit-stable
+constexpr int LT = 1024, LROWS = 256;
 __device__ __forceinline__ void loss_finalize_block(const float* __restrict__ part, int NB, int C, const float* cw,
                                                     int ignore_index, float smooth, float dice_weight, float ce_weight,
                                                     float* __restrict__ state, float* __restrict__ loss_out) {
   __shared__ double tot[LP];
-  __shared__ double sh[8][32];
+  __shared__ double sh[LT / 32][32];
   static_assert(LP <= 32, "one column lane per partial");
+  constexpr int RG = LT / 32, FL = LROWS / RG;
   const int t = threadIdx.x, cx = t & 31, ry = t >> 5;
   double acc = 0.0;
   if (cx < LP) {
-    // eight independent partial rows in flight per pass (the walk is latency-bound otherwise); the order of the additions
-    // stays fixed: bit-stable
-    double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int b = ry; b < NB; b += 64) {
-      float v[8];
+    float v[FL];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (b + 8 * u < NB) ? part[(size_t)(b + 8 * u) * LP + cx] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a8[u] += (double)v[u];
+    for (int u = 0; u < FL; ++u) {   // unconditional loads of a clamped row (a conditional load compiles to branch + wait)
+      const int r = ry + RG * u < NB ? ry + RG * u : NB - 1;
+      v[u] = part[(unsigned)r * LP + cx];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += a8[u];
+    for (int u = 0; u < FL; ++u) acc += (ry + RG * u < NB) ? (double)v[u] : 0.0;
   }
   sh[ry][cx] = acc;
   __syncthreads();
   if (t < LP) {
     double s = 0.0;
-    for (int r = 0; r < 8; ++r) s += sh[r][t];   // fixed order
+    for (int r = 0; r < RG; ++r) s += sh[r][t];   // fixed order
     tot[t] = s;
   }
   __syncthreads();
@@ -344,55 +359,102 @@ __device__ __forceinline__ void loss_finalize_block(const float* __restrict__ pa
 // PROB: the input already holds class probabilities (prompt model, prompt_based/prompt.py:33-56): Dice on the values
 // themselves (weighted_loss.py:206-209 with apply_softmax=False) and NLLLoss on nll_nonlin(x) = log(x + eps)
 // (nll_log, prompt.ipynb's stable_log) or on x itself (weighted_loss.py:338-340)
-template <bool PROB>
-__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ logits,
+// NC = compiled class count (>= C): the per-class work and the accumulators are sized to it, not to MAXC.  Two pixels per
+// thread are in flight per pass (the walk is latency-bound otherwise); additions stay in one fixed order: bit-stable.
+template <bool PROB, int NC>
+__global__ __launch_bounds__(LT) void loss_fwd_kernel(const float* __restrict__ logits,
                                                        const long long* __restrict__ labels,
                                                        const float* __restrict__ cw, long P, long HW, int C,
                                                        int ignore_index, float* __restrict__ part, int nll_log, float eps,
                                                        float smooth, float dice_weight, float ce_weight,
                                                        float* __restrict__ state, float* __restrict__ loss_out,
                                                        unsigned* __restrict__ ticket) {
-  __shared__ float sh[4];
+  __shared__ float sh[LT / 64][LP];
   __shared__ int last;
-  float acc[LP];
+  float a0 = 0.f, a1 = 0.f, aI[NC], aP[NC], aG[NC];
 #pragma unroll
-  for (int i = 0; i < LP; ++i) acc[i] = 0.f;
-  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+  for (int k = 0; k < NC; ++k) { aI[k] = 0.f; aP[k] = 0.f; aG[k] = 0.f; }
+  auto fetch = [&](long p, float (&raw)[NC], long long& y) {
     const long b = p / HW, r = p - b * HW;
-    float l[MAXC], raw[MAXC], m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      raw[k] = (k < C) ? logits[(b * C + k) * HW + r] : -INFINITY;
-      m = fmaxf(m, raw[k]);
+    for (int k = 0; k < NC; ++k) {   // unconditional loads (class index clamped), selected afterwards
+      const float v = logits[(b * C + (k < C ? k : C - 1)) * HW + r];
+      raw[k] = (k < C) ? v : -INFINITY;
     }
+    y = labels[p];
+  };
+  auto pixel = [&](const float (&raw)[NC], const long long y) {
+    float l[NC], m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) m = fmaxf(m, raw[k]);
     float se = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
+    for (int k = 0; k < NC; ++k) {
       if constexpr (PROB) l[k] = (k < C) ? raw[k] : 0.f;
       else l[k] = (k < C) ? expf(raw[k] - m) : 0.f;
       se += l[k];
     }
     const float inv = PROB ? 1.f : 1.f / se, lse = PROB ? 0.f : logf(se);
-    const long long y = labels[p];
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
+    for (int k = 0; k < NC; ++k) {
       const float pk = l[k] * inv;
       const float oh = (y == k) ? 1.f : 0.f;
-      acc[2 + k] += pk * oh;
-      acc[2 + MAXC + k] += pk;
-      acc[2 + 2 * MAXC + k] += oh;
+      aI[k] += pk * oh;
+      aP[k] += pk;
+      aG[k] += oh;
       if (y == k && k < C && y != ignore_index) {
         const float wy = cw ? cw[k] : 1.f;
-        if constexpr (PROB) acc[0] += wy * (nll_log ? -logf(raw[k] + eps) : -raw[k]);
-        else acc[0] += wy * (lse - (raw[k] - m));   // -log softmax = log(sum exp) - (logit - max)
-        acc[1] += wy;
+        if constexpr (PROB) a0 += wy * (nll_log ? -logf(raw[k] + eps) : -raw[k]);
+        else a0 += wy * (lse - (raw[k] - m));   // -log softmax = log(sum exp) - (logit - max)
+        a1 += wy;
       }
     }
+  };
+  // four pixels per thread in flight per pass (the walk is latency-bound otherwise); one fixed order of additions
+  const long step = (long)gridDim.x * LT;
+  long p = (long)blockIdx.x * LT + threadIdx.x;
+  for (; p + 3 * step < P; p += 4 * step) {
+    float r0[NC], r1[NC], r2[NC], r3[NC];
+    long long y0, y1, y2, y3;
+    fetch(p, r0, y0);
+    fetch(p + step, r1, y1);
+    fetch(p + 2 * step, r2, y2);
+    fetch(p + 3 * step, r3, y3);
+    pixel(r0, y0);
+    pixel(r1, y1);
+    pixel(r2, y2);
+    pixel(r3, y3);
   }
+  for (; p < P; p += step) {
+    float r0[NC];
+    long long y0;
+    fetch(p, r0, y0);
+    pixel(r0, y0);
+  }
+  // wave sums by butterfly, the wave rows through LDS, one row of LP partials per block (unused class slots = 0)
+  float v[LP];
+#pragma unroll
+  for (int i = 0; i < LP; ++i) v[i] = 0.f;
+  v[0] = a0; v[1] = a1;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { v[2 + k] = aI[k]; v[2 + MAXC + k] = aP[k]; v[2 + 2 * MAXC + k] = aG[k]; }
 #pragma unroll
   for (int i = 0; i < LP; ++i) {
-    const float s = block_sum(acc[i], sh);
-    if (threadIdx.x == 0) part[(size_t)blockIdx.x * LP + i] = s;
+    if (i >= 2 && ((i - 2) % MAXC) >= NC) continue;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < LP; ++i) sh[threadIdx.x >> 6][i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < LP) {
+    const int i = threadIdx.x;
+    float s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < LT / 64; ++w) s2 += sh[w][i];   // fixed order
+    part[(size_t)blockIdx.x * LP + i] = s2;
   }
   // the block that finishes last turns the partial rows into the loss (no second launch, nobody waits)
   if (last_arriver(ticket, gridDim.x, &last))
@@ -400,7 +462,7 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
 }
 
 
-template <bool PROB>
+template <bool PROB, int NC>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits,
                                                        const long long* __restrict__ labels,
                                                        const float* __restrict__ cw, const float* __restrict__ state,
@@ -409,9 +471,9 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ dlogits, int nll_log, float eps) {
   const float go = gout[0];
   const float ce_den = state[3];
-  float G0[MAXC], G1[MAXC];   // dL_dice/dp_k = G0 + onehot*G1
+  float G0[NC], G1[NC];   // dL_dice/dp_k = G0 + onehot*G1
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k) {
+  for (int k = 0; k < NC; ++k) {
     G0[k] = 0.f; G1[k] = 0.f;
     if (k < C) {
       const float dc = state[4 + k], den_raw = state[4 + MAXC + k], ak = state[4 + 2 * MAXC + k];
@@ -421,10 +483,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
   }
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
     const long b = p / HW, r = p - b * HW;
-    float l[MAXC], m = -INFINITY;
+    float l[NC], m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      l[k] = (k < C) ? logits[(b * C + k) * HW + r] : -INFINITY;
+    for (int k = 0; k < NC; ++k) {   // unconditional loads (class index clamped), selected afterwards
+      const float v = logits[(b * C + (k < C ? k : C - 1)) * HW + r];
+      l[k] = (k < C) ? v : -INFINITY;
       m = fmaxf(m, l[k]);
     }
     const long long y = labels[p];
@@ -433,7 +496,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     if (ce_valid) wy = (cw ? cw[y] : 1.f) / ce_den;
     if constexpr (PROB) {   // d/dx of  dice(x) + nll(log(x + eps) | x)
 #pragma unroll
-      for (int k = 0; k < MAXC; ++k)
+      for (int k = 0; k < NC; ++k)
         if (k < C) {
           const bool hit = (y == k);
           const float dd = G0[k] + (hit ? G1[k] : 0.f);
@@ -444,16 +507,16 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     }
     float se = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) { l[k] = (k < C) ? expf(l[k] - m) : 0.f; se += l[k]; }
+    for (int k = 0; k < NC; ++k) { l[k] = (k < C) ? expf(l[k] - m) : 0.f; se += l[k]; }
     const float inv = 1.f / se;
     float dot = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
+    for (int k = 0; k < NC; ++k) {
       l[k] *= inv;
       dot += l[k] * (G0[k] + ((y == k) ? G1[k] : 0.f));
     }
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k)
+    for (int k = 0; k < NC; ++k)
       if (k < C) {
         const float gk = G0[k] + ((y == k) ? G1[k] : 0.f);
         const float dd = l[k] * (gk - dot);
@@ -494,10 +557,13 @@ static bool raise_lds(const void* f) {
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifndef SEGK_HEAD_BLOCKS_CAP
+#define SEGK_HEAD_BLOCKS_CAP 1024
+#endif
 int segk_head_blocks(long P) {
   if (P <= 0) return 0;
   long g = (P + 31) / 32;
-  return (int)(g > 1024 ? 1024 : g);
+  return (int)(g > SEGK_HEAD_BLOCKS_CAP ? SEGK_HEAD_BLOCKS_CAP : g);
 }
 int segk_head_part_floats(long P, int Cp) {
   if (P <= 0 || Cp <= 0) return 0;
@@ -642,8 +708,8 @@ int segk_prompt_mix_impl(const float* clip, const float* mask, const float* dout
 
 int segk_loss_blocks(long P) {
   if (P <= 0) return 0;
-  long g = (P + 255) / 256;
-  return (int)(g > 512 ? 512 : g);
+  long g = (P + 4 * LT - 1) / (4 * LT);           // four pixels per thread per pass, at most LROWS partial rows
+  return (int)(g > LROWS ? LROWS : g < 1 ? 1 : g);
 }
 int segk_loss_part_floats(long P) { return segk_loss_blocks(P) * LP; }
 int segk_loss_state_floats(void) { return LS; }
@@ -657,8 +723,19 @@ int segk_loss_fwd_impl(const float* logits, const long long* labels, const float
   const int nb = segk_loss_blocks(P);
   unsigned* const ticket = segk_ticket_slot();
   SEGK_REQUIRE(ticket != nullptr, "loss_fwd: no ticket array");
-  if (prob) hipLaunchKernelGGL(loss_fwd_kernel<true>, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part, nll_log, eps, smooth, dice_weight, ce_weight, state, loss_out, ticket);
-  else hipLaunchKernelGGL(loss_fwd_kernel<false>, dim3(nb), dim3(256), 0, st, logits, labels, cw, P, HW, C, ignore_index, part, 0, 0.f, smooth, dice_weight, ce_weight, state, loss_out, ticket);
+  auto launch = [&](auto PROBc, auto NCc) {
+    constexpr bool PR = decltype(PROBc)::value;
+    constexpr int NC = decltype(NCc)::value;
+    hipLaunchKernelGGL((loss_fwd_kernel<PR, NC>), dim3(nb), dim3(LT), 0, st, logits, labels, cw, P, HW, C, ignore_index, part,
+                       PR ? nll_log : 0, PR ? eps : 0.f, smooth, dice_weight, ce_weight, state, loss_out, ticket);
+  };
+  auto by_nc = [&](auto PROBc) {
+    if (C <= 2) launch(PROBc, std::integral_constant<int, 2>{});
+    else if (C <= 4) launch(PROBc, std::integral_constant<int, 4>{});
+    else launch(PROBc, std::integral_constant<int, MAXC>{});
+  };
+  if (prob) by_nc(std::true_type{});
+  else by_nc(std::false_type{});
   SEGK_CHECK_LAUNCH("loss_fwd");
   return 0;
 }
@@ -670,8 +747,19 @@ int segk_loss_bwd_impl(const float* logits, const long long* labels, const float
   const long P = (long)N * HW;
   long g = (P + 255) / 256;
   if (g > 4096) g = 4096;
-  if (prob) hipLaunchKernelGGL(loss_bwd_kernel<true>, dim3((int)g), dim3(256), 0, st, logits, labels, cw, state, gout, P, HW, C, ignore_index, dice_weight, ce_weight, dlogits, nll_log, eps);
-  else hipLaunchKernelGGL(loss_bwd_kernel<false>, dim3((int)g), dim3(256), 0, st, logits, labels, cw, state, gout, P, HW, C, ignore_index, dice_weight, ce_weight, dlogits, 0, 0.f);
+  auto launch = [&](auto PROBc, auto NCc) {
+    constexpr bool PR = decltype(PROBc)::value;
+    constexpr int NC = decltype(NCc)::value;
+    hipLaunchKernelGGL((loss_bwd_kernel<PR, NC>), dim3((int)g), dim3(256), 0, st, logits, labels, cw, state, gout, P, HW, C,
+                       ignore_index, dice_weight, ce_weight, dlogits, PR ? nll_log : 0, PR ? eps : 0.f);
+  };
+  auto by_nc = [&](auto PROBc) {
+    if (C <= 2) launch(PROBc, std::integral_constant<int, 2>{});
+    else if (C <= 4) launch(PROBc, std::integral_constant<int, 4>{});
+    else launch(PROBc, std::integral_constant<int, MAXC>{});
+  };
+  if (prob) by_nc(std::true_type{});
+  else by_nc(std::false_type{});
   SEGK_CHECK_LAUNCH("loss_bwd");
   return 0;
 }

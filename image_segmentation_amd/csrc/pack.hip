@@ -208,9 +208,15 @@ __device__ __forceinline__ void wgrad_reduce_row(const float* __restrict__ slabs
   const int nvec = taps * Kp / 4;                // Kp % 32 == 0
   for (int v = threadIdx.x; v < nvec; v += 256) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = 0; t < S; ++t) {                // fixed order: bit-stable
-      const float4 x = *(const float4*)(base + (long)t * slab + (long)v * 4);
-      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    // eight slabs in flight (unconditional loads of a clamped slab index; left as a plain loop the compiler issues one load
+    // and waits for it: S serial round trips per vector); added in slab order: bit-stable
+    for (int t0 = 0; t0 < S; t0 += 8) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = *(const float4*)(base + (long)(t0 + u < S ? t0 + u : S - 1) * slab + (long)v * 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (t0 + u < S) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
     }
     const int e = v * 4, tap = e / Kp, kp = e - tap * Kp;
     const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
@@ -246,9 +252,14 @@ __device__ __forceinline__ void wgrad_reduce_wide(const float* __restrict__ slab
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (v < nvec) {
     const float* base = slabs + (long)n * taps * Kp + (long)v * 4;
-    for (int t = sl; t < S; t += 16) {
-      const float4 x = *(const float4*)(base + (long)t * slab);
-      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    // eight of the lane's slabs in flight (see wgrad_reduce_row); added in the old order: bit-stable
+    for (int t0 = sl; t0 < S; t0 += 128) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = *(const float4*)(base + (long)(t0 + 16 * u < S ? t0 + 16 * u : S - 1) * slab);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (t0 + 16 * u < S) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
     }
   }
   red[sl][vl] = acc;
@@ -288,9 +299,12 @@ __device__ __forceinline__ void colsum_block(const float* __restrict__ part, int
     for (int r = ry; r < rows; r += 256) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (r + 32 * u < rows) ? part[((size_t)(r + 32 * u) * Ctot + col0 + c) * 2] : 0.f;
+      for (int u = 0; u < 8; ++u) {   // unconditional loads of a clamped row (a conditional load compiles to branch + wait)
+        const int rr = r + 32 * u < rows ? r + 32 * u : rows - 1;
+        v[u] = part[((size_t)rr * Ctot + col0 + c) * 2];
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a8[u] += (double)v[u];
+      for (int u = 0; u < 8; ++u) a8[u] += (r + 32 * u < rows) ? (double)v[u] : 0.0;
     }
   double s = 0.0;
 #pragma unroll

@@ -94,8 +94,11 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 4) void stem_stream_kernel(const f
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const bool ok = ((kmask >> e) & 1u) & ((unsigned)(y + gdy[e]) < (unsigned)H) & ((unsigned)(xx + gdx[e]) < (unsigned)W);
-      v[e] = ok ? px[goff[e]] : 0.f;
+      const float g = px[ok ? goff[e] : 0];        // unconditional (a conditional load compiles to branch + load + wait)
+      v[e] = ok ? g : 0.f;
     }
+    float c0 = 0.f, c1r = 0.f, c2r = 0.f;          // side output: the pixel's own channels, fetched with the gathers
+    if (xn != nullptr) { c0 = px[0]; c1r = px[Cin > 1 ? HW : 0]; c2r = px[Cin > 2 ? 2 * HW : 0]; }
     const u32x4 bf = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
     f32x4 acc[4];
 #pragma unroll
@@ -115,9 +118,8 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 4) void stem_stream_kernel(const f
     if (xn != nullptr) {                           // padded NHWC copy of the input (32 channels: Cin real, zeros behind)
       u32x4 c = {0u, 0u, 0u, 0u};
       if (lq == 0) {
-        const float c0 = px[0], c1 = Cin > 1 ? px[HW] : 0.f, c2 = Cin > 2 ? px[2 * HW] : 0.f;
-        c.x = pk_bf16(c0, c1);
-        c.y = pk_bf16(c2, 0.f);
+        c.x = pk_bf16(c0, Cin > 1 ? c1r : 0.f);
+        c.y = pk_bf16(Cin > 2 ? c2r : 0.f, 0.f);
       }
       *(u32x4*)(xn + opix * 32 + lq * 8) = c;
     }
@@ -202,8 +204,15 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_wgrad_kernel(const fl
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = a.v[e]; v[4 + e] = c.v[e]; }
     } else {
+      // image border: unconditional loads from the row / column clamped into the image, selected afterwards (eight
+      // conditional loads compile to eight serial round trips)
+      const int yc = y + dy < 0 ? 0 : (y + dy >= H ? H - 1 : y + dy);
+      const float* rowp = x + ((size_t)(b * Cin + (jok ? ci : 0)) * H + yc) * W;
+      float g[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (rok && (unsigned)(xs + e) < (unsigned)W) ? src[e] : 0.f;
+      for (int e = 0; e < 8; ++e) { const int xc = xs + e < 0 ? 0 : (xs + e >= W ? W - 1 : xs + e); g[e] = rowp[xc]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (rok && (unsigned)(xs + e) < (unsigned)W) ? g[e] : 0.f;
     }
     *(uint4*)(slot + lp * 64 + lc4 * 16) = d0;
     *(uint4*)(slot + 1024 + lp * 64 + lc4 * 16) = d1;

@@ -128,6 +128,25 @@ def bn():
         print(f"bn_bwd C={C:5d}@{hw:3d}  {t:8.1f} us  {by/t/1e3:7.1f} GB/s (5 passes)")
 
 
+def loss():
+    """Loss forward / backward (CrossEntropy and Dice+CE) through the C ABI at the bench batch: 32 x 3 x 256 x 256 logits."""
+    N, C, H, W = 32, 3, 256, 256
+    lg = torch.randn((N, C, H, W), device="cuda")
+    tg = torch.randint(0, C, (N, H, W), device="cuda")
+    part = torch.empty(_lib.query("segk_loss_part_floats", N * H * W), device="cuda")
+    state = torch.empty(_lib.query("segk_loss_state_floats"), device="cuda")
+    out = torch.empty(1, device="cuda"); go = torch.ones(1, device="cuda"); dl = torch.empty_like(lg)
+    st = ops._stream()
+    for name, dw, cw in (("ce", 0.0, 1.0), ("dice+ce", 1.0, 1.0)):
+        f = lambda: _lib.call("segk_loss_fwd", lg.data_ptr(), tg.data_ptr(), None, N, C, H * W, -1, 1e-5, dw, cw,
+                              part.data_ptr(), state.data_ptr(), out.data_ptr(), st)
+        b = lambda: _lib.call("segk_loss_bwd", lg.data_ptr(), tg.data_ptr(), None, state.data_ptr(), go.data_ptr(), N, C,
+                              H * W, -1, dw, cw, dl.data_ptr(), st)
+        tf = timeit(f, 50); tb = timeit(b, 50)
+        print(f"loss {name:8s} fwd {tf:7.1f} us ({N*H*W*(4*C+8)/tf/1e3:7.1f} GB/s)   bwd {tb:7.1f} us ({N*H*W*(8*C+8)/tb/1e3:7.1f} GB/s)"
+              f"   value {float(out):.6f}")
+
+
 def pack():
     """Weight re-layout after an optimizer step: one-pass forward + data-gradient pack against the two per-mode packs,
     all 18 Conv3x3 weights of the U-Net."""
@@ -145,6 +164,9 @@ def pack():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pack":
         pack()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loss":
+        loss()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bn":
         bn()
