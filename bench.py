@@ -143,6 +143,25 @@ def run_workload(args, world, rank, dev, want_levels=False):
             if gs is not None:
                 overlap = gs.overlap_trace()
                 gs.timing = False
+    census = None
+    if want_levels and rank == 0 and world == 1:
+        # device-side launch census of the step (torch.profiler, 2 steps): every kernel the step puts on the GPU, the
+        # optimizer's and torch's fills / copies included -- the span count of `kernels` sees only this package's launches
+        from torch.profiler import profile, ProfilerActivity
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with profile(activities=[ProfilerActivity.CUDA]) as tp:
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+        names = {}
+        for e in tp.events():
+            if e.device_type is not None and str(e.device_type).endswith("CUDA"):
+                names[e.name] = names.get(e.name, 0) + 1
+        stock = sum(c for k, c in names.items() if "at::native" in k or k.startswith("Mem") or "rocclr" in k)
+        census = {"device_launches_per_step": sum(names.values()) / 2.0, "stock_torch_launches_per_step": stock / 2.0,
+                  "distinct_kernels": len(names), "method": "torch.profiler CUDA activity over 2 steps after the timed region"}
     if world > 1:
         dist.barrier()
     if gs is not None:
@@ -150,7 +169,7 @@ def run_workload(args, world, rank, dev, want_levels=False):
     del model, opt, X, Y
     torch.cuda.empty_cache()
     seg.set_compute_dtype(prev_dtype)
-    return {"dt": dt, "final_loss": final_loss, "prof": prof, "levels": level_prof, "overlap": overlap}
+    return {"dt": dt, "final_loss": final_loss, "prof": prof, "levels": level_prof, "overlap": overlap, "census": census}
 
 
 def family_table(prof, n, peak):
@@ -423,6 +442,7 @@ def main():
                    "ranks": ranks_info, "rehearsal": rehearsal},
         "roofline": roofline, "cpu_baseline": cpu, "doubleconv_scope": scope, "kernels": kernels,
         "launches_per_step": sum(k["launches_per_step"] for k in kernels.values()) if kernels else None,
+        "launch_census": w.get("census"),
         "levels": levels, "other_configs": extras, "clock": clock, "allreduce_overlap": overlap,
     }
     print(json.dumps(out))
