@@ -402,12 +402,9 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __rest
   const int Ho = H >> 1, Wo = W >> 1, CV = C / E::VEC;
   const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;   // also visit the odd border (no pooled output there)
   const long total = (long)B * Hc * Wc * CV;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    long p = i / CV;
-    const int xo = (int)(p % Wc); p /= Wc;
-    const int yo = (int)(p % Hc);
-    const int b = (int)(p / Hc);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+    const Idx4 ix = split4(i, (unsigned)CV, (unsigned)Wc, (unsigned)Hc);
+    const int cv = ix.cv, xo = ix.x, yo = ix.y, b = ix.b;
     float sc[E::VEC], sh[E::VEC], mx[E::VEC];
 #pragma unroll
     for (int j = 0; j < E::VEC; ++j) { sc[j] = scale[cv * E::VEC + j]; sh[j] = shift[cv * E::VEC + j]; mx[j] = 0.f; }
@@ -447,12 +444,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   using E = ET<T>;
   const int Ho = H >> 1, Wo = W >> 1, CV = C / E::VEC;
   const long total = (long)B * Ho * Wo * CV;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    long p = i / CV;
-    const int xo = (int)(p % Wo); p /= Wo;
-    const int yo = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+    const Idx4 ix = split4(i, (unsigned)CV, (unsigned)Wo, (unsigned)Ho);
+    const int cv = ix.cv, xo = ix.x, yo = ix.y, b = ix.b;
     const T* src = x + (((size_t)(b * H + 2 * yo)) * W + 2 * xo) * C + cv * E::VEC;
     float f0[E::VEC], f1[E::VEC], f2[E::VEC], f3[E::VEC];
     unpack16<T>(*(const uint4*)src, f0);
@@ -504,12 +498,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 #ifdef SEGK_POOL_NO_Z
   from_z = false;                                  // diagnostic build: the kernel without its rare path (A/B of its cost)
 #endif
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    long p = i / CV;
-    const int xo = (int)(p % Wc); p /= Wc;
-    const int yo = (int)(p % Hc);
-    const int b = (int)(p / Hc);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+    const Idx4 ix = split4(i, (unsigned)CV, (unsigned)Wc, (unsigned)Hc);
+    const int cv = ix.cv, xo = ix.x, yo = ix.y, b = ix.b;
     const bool inwin = (yo < Ho) && (xo < Wo);
     // every load of the window is issued before any is used, unconditionally, from coordinates clamped into the image (a
     // load under a per-lane condition compiles to branch + load + wait: nine serial memory round trips per window)
@@ -568,12 +559,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
       // them visible to it), y for the ReLU mask, and z
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) sgx[j] = 0.f;
-      for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int cv = (int)(i % CV);
-        long p = i / CV;
-        const int xo = (int)(p % Wc); p /= Wc;
-        const int yo = (int)(p % Hc);
-        const int b = (int)(p / Hc);
+      for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+        const Idx4 ix = split4(i, (unsigned)CV, (unsigned)Wc, (unsigned)Hc);
+        const int cv = ix.cv, xo = ix.x, yo = ix.y, b = ix.b;
         for (int k = 0; k < 4; ++k) {
           const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
           if (yy >= H || xx >= W) continue;
@@ -731,6 +719,7 @@ int segk_bn_relu_apply_pool_impl(const void* z, void* y, void* pooled, const flo
                "bn_relu_apply_pool: bad arguments");
   const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
   long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec);
+  SEGK_REQUIRE(total < (1L << 31), "bn_relu_apply_pool: more than 2^31 windows x channel vectors");
   long g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   if (dtype == SEGK_DT_BF16)
@@ -819,6 +808,7 @@ int segk_maxpool_fwd_impl(const void* x, void* y, int B, int H, int W, int C, in
   SEGK_REQUIRE(x && y && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 32 == 0, "maxpool_fwd: bad arguments");
   const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
   long total = (long)B * (H / 2) * (W / 2) * (C / vec);
+  SEGK_REQUIRE(total < (1L << 31), "maxpool_fwd: more than 2^31 windows x channel vectors");
   long g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   if (dtype == SEGK_DT_BF16)
@@ -834,6 +824,7 @@ int segk_maxpool_bwd_impl(const void* x, const void* dy, void* dx, int B, int H,
   SEGK_REQUIRE(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 32 == 0, "maxpool_bwd: bad arguments");
   const int vec = dtype == SEGK_DT_BF16 ? 8 : 4;
   long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec);
+  SEGK_REQUIRE(total < (1L << 31), "maxpool_bwd: more than 2^31 windows x channel vectors");
   long g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   if (dtype == SEGK_DT_BF16)
@@ -853,6 +844,7 @@ int segk_maxpool_bwd_stat_blocks(int B, int H, int W, int C, int dtype) {
   const int cv = C / vec;
   if ((cv & (cv - 1)) != 0 || cv > 256) return 0;
   long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * cv;
+  if (total >= (1L << 31)) return 0;                  // the kernels index windows x channel vectors with 32 bits
   long g = (total + 255) / 256;
   return (int)(g > 1024 ? 1024 : g);
 }

@@ -59,12 +59,17 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, flo
   f[4] = bf2f(v.z & 0xffffu); f[5] = __uint_as_float(v.z & 0xffff0000u);
   f[6] = bf2f(v.w & 0xffffu); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
-  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
-  uint16_t ua = __builtin_bit_cast(uint16_t, a), ub = __builtin_bit_cast(uint16_t, b);
-  return (uint32_t)ua | ((uint32_t)ub << 16);
+// Two floats -> one packed bf16 pair (round to nearest even, NaN-preserving): ONE v_cvt_pk_bf16_f32, emitted by the compiler
+// from a vector conversion.  Never write this instruction as inline asm on accumulator values: the compiler inserts the
+// wait states an MFMA result needs before a VALU read only for instructions it knows -- an asm statement placed right behind
+// the MFMA reads the register before the matrix pipe has written it (round 3: the ConvTranspose streaming kernel produced
+// garbage as soon as the 64-bit index arithmetic that used to sit between the two was shortened).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){lo, hi}, bf16x2v));
 }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
   return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
@@ -96,8 +101,7 @@ __device__ __forceinline__ void stage_frag(const float (&v)[16], char* obase, in
     p1 += x;
     p2 = __builtin_elementwise_fma(x, x, p2);
     if constexpr (sizeof(T) == 2) {
-      uint32_t pk;   // ONE conversion for the pair (the compiler otherwise converts each half on its own)
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x.x), "v"(x.y));
+      const uint32_t pk = cvt_pk_bf16(x.x, x.y);   // ONE conversion for the pair
       *(uint16_t*)(obase + dm * OP) = (uint16_t)(pk & 0xffffu);
       *(uint16_t*)(obase + (dm + 1) * OP) = (uint16_t)(pk >> 16);
     } else {
@@ -116,4 +120,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Item index -> (channel vector, x, y, image) in 32-bit arithmetic.  A 64-bit division by a run-time value is a ~130-
+// instruction loop on this ISA, and a streaming kernel that decomposes a `long` index per item (five div/mod) spends more
+// VALU time on that than on its data; every launcher that uses this checks that its item count is below 2^31.
+struct Idx4 { int cv, x, y, b; };
+__device__ __forceinline__ Idx4 split4(unsigned i, unsigned CV, unsigned Wc, unsigned Hc) {
+  const unsigned p = i / CV, q = p / Wc, b = q / Hc;
+  Idx4 r;
+  r.cv = (int)(i - p * CV); r.x = (int)(p - q * Wc); r.y = (int)(q - b * Hc); r.b = (int)b;
+  return r;
+}
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

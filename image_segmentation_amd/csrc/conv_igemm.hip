@@ -959,8 +959,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
         }
         char* const ob = ot + m0 * OP + n * E::ES;
         uint32_t p01, p23;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p01) : "v"(v[0]), "v"(v[1]));
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p23) : "v"(v[2]), "v"(v[3]));
+        p01 = cvt_pk_bf16(v[0], v[1]);
+        p23 = cvt_pk_bf16(v[2], v[3]);
         *(uint16_t*)(ob) = (uint16_t)(p01 & 0xffffu);
         *(uint16_t*)(ob + OP) = (uint16_t)(p01 >> 16);
         *(uint16_t*)(ob + 2 * OP) = (uint16_t)(p23 & 0xffffu);

@@ -104,10 +104,10 @@ __device__ __forceinline__ int fresh_lane() {
 // 8 floats -> 8 bf16 (round to nearest even, NaN-preserving), one v_cvt_pk_bf16_f32 per pair
 __device__ __forceinline__ uint4 pack8_bf16(const float (&v)[8]) {
   uint4 o;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v[0]), "v"(v[1]));
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v[2]), "v"(v[3]));
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.z) : "v"(v[4]), "v"(v[5]));
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.w) : "v"(v[6]), "v"(v[7]));
+  o.x = cvt_pk_bf16(v[0], v[1]);
+  o.y = cvt_pk_bf16(v[2], v[3]);
+  o.z = cvt_pk_bf16(v[4], v[5]);
+  o.w = cvt_pk_bf16(v[6], v[7]);
   return o;
 }
 
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
         const float f1 = fmaxf(fmaf(__uint_as_float(raw.x & 0xffff0000u), __uint_as_float(tsc.y), __uint_as_float(tsh.y)), 0.f);
         const float f2 = fmaxf(fmaf(bf2f(raw.y & 0xffffu), __uint_as_float(tsc.z), __uint_as_float(tsh.z)), 0.f);
         const float f3 = fmaxf(fmaf(__uint_as_float(raw.y & 0xffff0000u), __uint_as_float(tsc.w), __uint_as_float(tsh.w)), 0.f);
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.x) : "v"(f0), "v"(f1));
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.y) : "v"(f2), "v"(f3));
+        v.x = cvt_pk_bf16(f0, f1);
+        v.y = cvt_pk_bf16(f2, f3);
       }
       __builtin_amdgcn_sched_barrier(0);
       lds_rd128<16>(tsc, taba);
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(512, 2) void conv_rs_kernel(const ConvArgs a) {
         const float f1 = fmaxf(fmaf(__uint_as_float(raw.z & 0xffff0000u), __uint_as_float(tsc.y), __uint_as_float(tsh.y)), 0.f);
         const float f2 = fmaxf(fmaf(bf2f(raw.w & 0xffffu), __uint_as_float(tsc.z), __uint_as_float(tsh.z)), 0.f);
         const float f3 = fmaxf(fmaf(__uint_as_float(raw.w & 0xffff0000u), __uint_as_float(tsc.w), __uint_as_float(tsh.w)), 0.f);
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.z) : "v"(f0), "v"(f1));
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.w) : "v"(f2), "v"(f3));
+        v.z = cvt_pk_bf16(f0, f1);
+        v.w = cvt_pk_bf16(f2, f3);
       }
       v = ok ? v : make_uint4(0u, 0u, 0u, 0u);
       lds_wr128<0>(posa, v);

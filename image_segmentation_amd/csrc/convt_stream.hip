@@ -51,21 +51,22 @@ __global__ __launch_bounds__(512, 2) void convt_stream_kernel(const bf16_t* __re
     for (int j = 0; j < 4; ++j) bs[nb][j] = (MODE == 0 && bias4) ? bias4[p * 32 + 8 * lq + 4 * half + j] : 0.f;   // rows 4 lq + j of D
   }
 
-  const long total = (long)nblocks16;              // 16-pixel blocks: W % 16 == 0, so a block never leaves its image row
-  const long step = (long)gridDim.x * streams;
-  long pb = (long)blockIdx.x * streams + stream;
+  // 32-bit block arithmetic (nblocks16 is an int): 64-bit divisions by W16 / H are ~130-instruction loops, two per block
+  const unsigned total = (unsigned)nblocks16;      // 16-pixel blocks: W % 16 == 0, so a block never leaves its image row
+  const unsigned step = gridDim.x * streams;
+  unsigned pb = blockIdx.x * streams + stream;
   if (pb >= total) return;
   u32x4 xf0[KS], xf1[KS];                          // ping-pong by code, not by index (a run-time index would put them in scratch)
   const int W16 = W / 16;
-  auto load_x = [&](long blk, u32x4 (&f)[KS]) {
+  auto load_x = [&](unsigned blk, u32x4 (&f)[KS]) {
     if constexpr (MODE == 0) {
       const bf16_t* src = x + ((size_t)blk * 16 + lc) * K + lq * 8;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) f[ks] = *(const u32x4*)(src + ks * 32);
     } else {
-      const long row = blk / W16;                  // b * H + y of the INPUT grid
+      const unsigned row = blk / (unsigned)W16;    // b * H + y of the INPUT grid
       const int xi = (int)(blk - row * W16) * 16 + lc;
-      const long b = row / H;
+      const unsigned b = row / (unsigned)H;
       const int y = (int)(row - b * H);
       const int cpt = Cout / 32;                   // k-steps per tap
 #pragma unroll
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void convt_stream_kernel(const bf16_t* __re
     }
   };
   // one 16-pixel block: the next block's loads go out first, then K/32 x NBW MFMAs, then NBW/2 sixteen-byte stores per lane
-  auto block = [&](long blk, const u32x4 (&cur)[KS], u32x4 (&nxt)[KS]) {
+  auto block = [&](unsigned blk, const u32x4 (&cur)[KS], u32x4 (&nxt)[KS]) {
     if (blk + step < total) load_x(blk + step, nxt);
     f32x4 acc[NBW];
 #pragma unroll
@@ -89,9 +90,9 @@ __global__ __launch_bounds__(512, 2) void convt_stream_kernel(const bf16_t* __re
         acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][nb]),
                                                           __builtin_bit_cast(bf16x8, cur[ks]), acc[nb], 0, 0, 0);
     // input pixel of this lane's column: block blk = (b, y, x0 / 16)
-    const long row = blk / W16;                    // b * H + y
+    const unsigned row = blk / (unsigned)W16;      // b * H + y
     const int x0 = (int)(blk - row * W16) * 16 + lc;
-    const long b = row / H;
+    const unsigned b = row / (unsigned)H;
     const int y = (int)(row - b * H);
 #pragma unroll
     for (int pp = 0; pp < NBW / 2; ++pp) {
@@ -99,10 +100,10 @@ __global__ __launch_bounds__(512, 2) void convt_stream_kernel(const bf16_t* __re
       const int tap = n_base / Cout, co = n_base - tap * Cout + 8 * lq;
       const f32x4 a0 = acc[2 * pp], a1 = acc[2 * pp + 1];
       u32x4 v;
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.x) : "v"(a0[0]), "v"(a0[1]));
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.y) : "v"(a0[2]), "v"(a0[3]));
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.z) : "v"(a1[0]), "v"(a1[1]));
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v.w) : "v"(a1[2]), "v"(a1[3]));
+      v.x = cvt_pk_bf16(a0[0], a0[1]);
+      v.y = cvt_pk_bf16(a0[2], a0[3]);
+      v.z = cvt_pk_bf16(a1[0], a1[1]);
+      v.w = cvt_pk_bf16(a1[2], a1[3]);
       if constexpr (MODE == 0) {
         const size_t opix = ((size_t)(b * 2 * H + 2 * y + (tap >> 1))) * (2 * W) + 2 * x0 + (tap & 1);
         *(u32x4*)(out + opix * Cout + co) = v;

@@ -20,6 +20,14 @@ constexpr int MAXC = 8;    // classes supported by the fused kernels
 constexpr int HT = 256;    // pixels per head tile (one per thread)
 constexpr int HCH = 64;    // channels staged per pass
 
+// pixel index -> (image, offset inside the image) with ONE 32-bit division: a 64-bit one is a ~130-instruction loop, per
+// pixel more than the rest of a loss kernel's arithmetic.  Every launcher below requires P < 2^31.
+__device__ __forceinline__ void split_hw(long p, long HW, long& b, long& r) {
+  const unsigned bb = (unsigned)p / (unsigned)HW;
+  b = (long)bb;
+  r = p - (long)bb * HW;
+}
+
 // ------------------------------------------------------------------------------------------------
 // logits[b][k][y][x] = bias[k] + sum_c y[p][c] * Wt[k][c]
 // NC = compiled class count (>= ncls): the per-class loops are unrolled to it, not to MAXC
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
     }
     const long p = p0 + tid;
     if (p < P) {
-      const long b = p / HW, r = p - b * HW;
+      long b, r; split_hw(p, HW, b, r);
 #pragma unroll
       for (int k = 0; k < NC; ++k)
         if (k < ncls) logits[(b * ncls + k) * HW + r] = acc[k];
@@ -185,30 +193,40 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         }
       }
     };
-    auto load_dl = [&](long p, float (&dl)[NC]) {
-      const long b = p / HW, r = p - b * HW;
+    // (image, offset) of a pixel stream is carried along instead of divided out per pixel: no division in the loop
+    auto load_dl = [&](long b, long r, float (&dl)[NC]) {
 #pragma unroll
       for (int k = 0; k < NC; ++k) {   // unconditional loads (class index clamped), selected afterwards
         const float v = dlog[(b * ncls + (k < ncls ? k : ncls - 1)) * HW + r];
         dl[k] = (k < ncls) ? v : 0.f;
       }
     };
+    auto advance = [&](long& b, long& r, long d) {
+      r += d;
+      while (r >= HW) { r -= HW; ++b; }
+    };
     // two pixels per iteration: both loads are in flight before either is used (the loop is latency-bound otherwise)
     const long step = (long)gridDim.x * rows;
     long p = (long)blockIdx.x * rows + ry;
+    long bA = 0, rA = 0;
+    if (p < P) split_hw(p, HW, bA, rA);
+    long bB = bA, rB = rA;
+    advance(bB, rB, step);
     for (; p + step < P; p += 2 * step) {
       float dl0[NC], dl1[NC];
       const uint4 r0 = *(const uint4*)(y + (size_t)p * Cp + cv * E::VEC);
       const uint4 r1 = *(const uint4*)(y + (size_t)(p + step) * Cp + cv * E::VEC);
-      load_dl(p, dl0);
-      load_dl(p + step, dl1);
+      load_dl(bA, rA, dl0);
+      load_dl(bB, rB, dl1);
       pixel(p, dl0, r0);
       pixel(p + step, dl1, r1);
+      advance(bA, rA, 2 * step);
+      advance(bB, rB, 2 * step);
     }
     if (p < P) {
       float dl0[NC];
       const uint4 r0 = *(const uint4*)(y + (size_t)p * Cp + cv * E::VEC);
-      load_dl(p, dl0);
+      load_dl(bA, rA, dl0);
       pixel(p, dl0, r0);
     }
   }
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(LT) void loss_fwd_kernel(const float* __restrict__ 
 #pragma unroll
   for (int k = 0; k < NC; ++k) { aI[k] = 0.f; aP[k] = 0.f; aG[k] = 0.f; }
   auto fetch = [&](long p, float (&raw)[NC], long long& y) {
-    const long b = p / HW, r = p - b * HW;
+    long b, r; split_hw(p, HW, b, r);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {   // unconditional loads (class index clamped), selected afterwards
       const float v = logits[(b * C + (k < C ? k : C - 1)) * HW + r];
@@ -482,7 +500,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     }
   }
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
-    const long b = p / HW, r = p - b * HW;
+    long b, r; split_hw(p, HW, b, r);
     float l[NC], m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < NC; ++k) {   // unconditional loads (class index clamped), selected afterwards
@@ -534,7 +552,7 @@ __global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict_
   if (threadIdx.x < MAXC * MAXC) hist[threadIdx.x] = 0;
   __syncthreads();
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
-    const long b = p / HW, r = p - b * HW;
+    long b, r; split_hw(p, HW, b, r);
     int best = 0;
     float bv = logits[(b * C) * HW + r];
     for (int k = 1; k < C; ++k) {
@@ -579,6 +597,7 @@ int segk_head_fwd_impl(const void* y, const float* w, const float* bias, float* 
   SEGK_REQUIRE(ncls >= 1 && ncls <= MAXC, "head_fwd: 1..%d classes supported, got %d", MAXC, ncls);
   SEGK_REQUIRE(Cp % 32 == 0 && C > 0 && C <= Cp, "head_fwd: bad channels");
   const long P = (long)B * H * W, HW = (long)H * W;
+  SEGK_REQUIRE(P < (1L << 31), "head / loss kernels index pixels with 32 bits: %ld pixels", P);
   long g = (P + HT - 1) / HT;
   if (g > 4096) g = 4096;
   // kernels are compiled for 2, 3, 4 and MAXC classes: the smallest that holds ncls
@@ -643,6 +662,7 @@ int segk_head_bwd_impl(const float* dlog, const void* y, const float* w, void* d
   SEGK_REQUIRE(!(bnpart || zin) || (bn_scale && bn_shift && bn_mean && bn_rstd),
                "head_bwd: BatchNorm reductions / a pre-activation input need scale, shift, mean and rstd");
   const long P = (long)B * H * W, HW = (long)H * W;
+  SEGK_REQUIRE(P < (1L << 31), "head / loss kernels index pixels with 32 bits: %ld pixels", P);
   const float* bn[4] = {bn_scale, bn_shift, bn_mean, bn_rstd};
   const float* const* bnp = (bnpart || zin) ? bn : nullptr;
   return dtype == SEGK_DT_BF16 ? head_bwd_t<bf16_t>(dlog, y, w, dy, part, dw, db, P, HW, Cp, C, ncls, bnp, bnpart, zin != 0, st)
@@ -656,7 +676,7 @@ int segk_head_blocks_q(long P) { return segk_head_blocks(P); }
 __global__ __launch_bounds__(256) void prompt_mix_fwd_kernel(const float* __restrict__ clip, const float* __restrict__ mask,
                                                              float* __restrict__ out, long P, long HW) {
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
-    const long b = p / HW, r = p - b * HW;
+    long b, r; split_hw(p, HW, b, r);
     float l[4], mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { l[k] = clip[(b * 4 + k) * HW + r]; mx = fmaxf(mx, l[k]); }
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(256) void prompt_mix_bwd_kernel(const float* __rest
                                                              const float* __restrict__ dout, float* __restrict__ dmask,
                                                              long P, long HW) {
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
-    const long b = p / HW, r = p - b * HW;
+    long b, r; split_hw(p, HW, b, r);
     float l[4], mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { l[k] = clip[(b * 4 + k) * HW + r]; mx = fmaxf(mx, l[k]); }
@@ -698,6 +718,7 @@ __global__ __launch_bounds__(256) void prompt_mix_bwd_kernel(const float* __rest
 int segk_prompt_mix_impl(const float* clip, const float* mask, const float* dout, float* out, int N, long HW, hipStream_t st) {
   SEGK_REQUIRE(clip && mask && out && N > 0 && HW > 0, "prompt_mix: bad arguments");
   const long P = (long)N * HW;
+  SEGK_REQUIRE(P < (1L << 31), "head / loss kernels index pixels with 32 bits: %ld pixels", P);
   long g = (P + 255) / 256;
   if (g > 4096) g = 4096;
   if (dout) hipLaunchKernelGGL(prompt_mix_bwd_kernel, dim3((int)g), dim3(256), 0, st, clip, mask, dout, out, P, HW);
@@ -720,6 +741,7 @@ int segk_loss_fwd_impl(const float* logits, const long long* labels, const float
   SEGK_REQUIRE(logits && labels && part && state && N > 0 && HW > 0, "loss_fwd: bad arguments");
   SEGK_REQUIRE(C >= 1 && C <= MAXC, "loss_fwd: 1..%d classes supported, got %d", MAXC, C);
   const long P = (long)N * HW;
+  SEGK_REQUIRE(P < (1L << 31), "head / loss kernels index pixels with 32 bits: %ld pixels", P);
   const int nb = segk_loss_blocks(P);
   unsigned* const ticket = segk_ticket_slot();
   SEGK_REQUIRE(ticket != nullptr, "loss_fwd: no ticket array");
@@ -745,6 +767,7 @@ int segk_loss_bwd_impl(const float* logits, const long long* labels, const float
                        float* dlogits, int prob, int nll_log, float eps, hipStream_t st) {
   SEGK_REQUIRE(logits && labels && state && gout && dlogits && N > 0 && HW > 0 && C >= 1 && C <= MAXC, "loss_bwd: bad arguments");
   const long P = (long)N * HW;
+  SEGK_REQUIRE(P < (1L << 31), "head / loss kernels index pixels with 32 bits: %ld pixels", P);
   long g = (P + 255) / 256;
   if (g > 4096) g = 4096;
   auto launch = [&](auto PROBc, auto NCc) {
@@ -768,6 +791,7 @@ int segk_confusion_impl(const float* logits, const long long* labels, int N, int
                         hipStream_t st) {
   SEGK_REQUIRE(logits && labels && M && N > 0 && HW > 0 && C >= 1 && C <= MAXC, "confusion: bad arguments");
   const long P = (long)N * HW;
+  SEGK_REQUIRE(P < (1L << 31), "head / loss kernels index pixels with 32 bits: %ld pixels", P);
   long g = (P + 255) / 256;
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(confusion_kernel, dim3((int)g), dim3(256), 0, st, logits, labels, P, HW, C, M);

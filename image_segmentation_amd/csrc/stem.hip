@@ -32,12 +32,13 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  return cvt_pk_bf16(a, b);      // compiler-visible (common.hpp): an asm conversion behind an MFMA reads too early
 }
 
 constexpr int STEM_WAVES = 8;
+#ifndef STEM_WG_PER_CU
+#define STEM_WG_PER_CU 2
+#endif
 
 __global__ __launch_bounds__(STEM_WAVES * 64, 4) void stem_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                          bf16_t* __restrict__ z, bf16_t* __restrict__ xn,
@@ -83,11 +84,12 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 4) void stem_stream_kernel(const f
     for (int j = 0; j < 8; ++j) { s1[p][j] = 0.f; s2[p][j] = 0.f; }
 
   const int W16 = W / 16;
-  const long step = (long)gridDim.x * STEM_WAVES;
-  for (long blk = (long)blockIdx.x * STEM_WAVES + wave; blk < nblk; blk += step) {
-    const long row = blk / W16;                    // b * H + y
+  // 32-bit block arithmetic (nblk < 2^31 by the launcher's shape check): a 64-bit division is a ~130-instruction loop
+  const unsigned step = gridDim.x * STEM_WAVES;
+  for (unsigned blk = blockIdx.x * STEM_WAVES + wave; blk < (unsigned)nblk; blk += step) {
+    const unsigned row = blk / (unsigned)W16;      // b * H + y
     const int xx = (int)(blk - row * W16) * 16 + lc;
-    const long b = row / H;
+    const unsigned b = row / (unsigned)H;
     const int y = (int)(row - b * H);
     const float* px = x + (size_t)b * Cin * HW + (size_t)y * W + xx;
     float v[8];
@@ -185,11 +187,11 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_wgrad_kernel(const fl
     for (int r = 0; r < 16; ++r) acc[nh][r] = 0.f;
 
   const int W16 = W / 16;
-  const long step = (long)gridDim.x * STEM_WAVES;
-  for (long blk = (long)blockIdx.x * STEM_WAVES + wave; blk < nblk; blk += step) {
-    const long row = blk / W16;                    // b * H + y
+  const unsigned step = gridDim.x * STEM_WAVES;    // 32-bit block arithmetic, see stem_stream_kernel
+  for (unsigned blk = blockIdx.x * STEM_WAVES + wave; blk < (unsigned)nblk; blk += step) {
+    const unsigned row = blk / (unsigned)W16;      // b * H + y
     const int x0 = (int)(blk - row * W16) * 16;
-    const long b = row / H;
+    const unsigned b = row / (unsigned)H;
     const int y = (int)(row - b * H);
     // ---- dz: 16 pixels x 64 channels -> LDS, natural [block][pixel][64 B]
     const bf16_t* dp = dz + ((size_t)row * W + x0 + lp) * 64 + lc4 * 8;
@@ -306,7 +308,7 @@ int segk_stem_rows(int B, int H, int W, int Cin, int Cout, int dtype) {
   if ((long long)B * H * W * 64 >= 2147483647LL * 16 || (long long)Cin * H * W >= 2147483647LL) return 0;
   const long nblk = (long)B * H * (W / 16);
   long g = (nblk + STEM_WAVES - 1) / STEM_WAVES;
-  const long cap = (long)segk_num_cus() * 2;       // two 8-wave workgroups per CU (four waves per SIMD: the gathers want many in flight)
+  const long cap = (long)segk_num_cus() * STEM_WG_PER_CU;   // 8-wave workgroups per CU: the gathers want many in flight
   if (g > cap) g = cap;
   return (int)(g > 1024 ? 1024 : g);               // <= 1024 rows: the one-block statistics finalisation
 }

@@ -421,7 +421,7 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
     for (int i = 0; i < 4; ++i) {
       const float x0 = fmaf(f[2 * i], psc, psh), x1 = fmaf(f[2 * i + 1], psc, psh);
       unsigned pk;
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x0), "v"(x1));
+      pk = cvt_pk_bf16(x0, x1);
       o[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2){0, 0}));
     }
     if (vmask != 0xffu) {

@@ -93,3 +93,19 @@ def test_streaming_and_finalize_kernels_keep_their_loads_in_flight():
     for unit in ("bn_pool", "head_loss", "pack", "stem"):
         for r in rep.report(unit):
             assert int(r.get("VGPRs Spill", 0)) == 0 and int(r.get("ScratchSize", 0)) == 0, (unit, r)
+
+
+def test_no_inline_asm_arithmetic_on_vector_registers():
+    """Inline-asm VALU instructions are invisible to the compiler's hazard recogniser: placed right behind an MFMA they read
+    the accumulator before the matrix pipe has written it (round 3: `v_cvt_pk_bf16_f32` as asm in the ConvTranspose streaming
+    kernel returned garbage once the index arithmetic between MFMA and conversion got shorter).  Conversions go through
+    `cvt_pk_bf16()` (a vector conversion the compiler lowers to the same instruction, with the wait states); the only VALU
+    asm allowed is the lane-id idiom."""
+    bad = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "image_segmentation_amd", "csrc", "*.h*"))):
+        for ln, line in enumerate(open(path), 1):
+            code = line.split("//")[0]
+            m = re.search(r'asm[^"]*"\s*(v_\w+)', code)
+            if m and not m.group(1).startswith("v_mbcnt"):
+                bad.append((os.path.basename(path), ln, m.group(1)))
+    assert not bad, bad

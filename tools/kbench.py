@@ -147,6 +147,31 @@ def loss():
               f"   value {float(out):.6f}")
 
 
+def head():
+    """Output head on the pre-activation of the last block (forward: BN+ReLU + 1x1 conv to 3 classes; backward incl. the
+    BatchNorm reductions) through the C ABI at the bench shape: B = 32, 64 channels, 256 x 256."""
+    B, C, H, W, ncls = 32, 64, 256, 256, 3
+    dt = torch.bfloat16
+    P = B * H * W
+    z = torch.randn((P, C), device="cuda").to(dt)
+    w = torch.randn((ncls, C), device="cuda") / 8; b = torch.zeros(ncls, device="cuda")
+    sc = torch.rand(C, device="cuda") + 0.5; sh = torch.rand(C, device="cuda") - 0.5
+    mu = torch.zeros(C, device="cuda"); rs = torch.ones(C, device="cuda")
+    logits = torch.empty((B, ncls, H, W), device="cuda"); dl = torch.randn_like(logits)
+    dy = torch.empty_like(z)
+    part = torch.empty(_lib.query("segk_head_part_floats", P, C), device="cuda")
+    nb = _lib.query("segk_head_bwd_blocks", P)
+    bnpart = torch.empty(nb * C * 2, device="cuda"); dw = torch.empty((ncls, C), device="cuda"); db = torch.empty(ncls, device="cuda")
+    st = ops._stream()
+    f = lambda: _lib.call("segk_head_fwd_bn", z.data_ptr(), sc.data_ptr(), sh.data_ptr(), w.data_ptr(), b.data_ptr(),
+                          logits.data_ptr(), B, H, W, C, C, ncls, 1, st)
+    g = lambda: _lib.call("segk_head_bwd_bn", dl.data_ptr(), z.data_ptr(), w.data_ptr(), dy.data_ptr(), part.data_ptr(),
+                          dw.data_ptr(), db.data_ptr(), B, H, W, C, C, ncls, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
+                          rs.data_ptr(), bnpart.data_ptr(), 1, st)
+    tf = timeit(f, 30); tb = timeit(g, 30)
+    print(f"head fwd {tf:7.1f} us ({P*(2*C+4*ncls)/tf/1e3:7.1f} GB/s)   bwd {tb:7.1f} us ({P*(4*C+4*ncls)/tb/1e3:7.1f} GB/s)")
+
+
 def pack():
     """Weight re-layout after an optimizer step: one-pass forward + data-gradient pack against the two per-mode packs,
     all 18 Conv3x3 weights of the U-Net."""
@@ -164,6 +189,9 @@ def pack():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pack":
         pack()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "head":
+        head()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "loss":
         loss()
