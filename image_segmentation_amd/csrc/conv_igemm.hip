@@ -1335,11 +1335,13 @@ int launch_pipe_m(ConvArgs a, hipStream_t st) {
 
 template <int TWL, bool PRO, int BN>
 int launch_pipe(ConvArgs a, hipStream_t st) {
-  // 16x16x32 consumers where the layer is MFMA-bound (K = 9 Cin long: same-box A/B 1024->1024@16 119 vs 132 us,
-  // 512->512@32 128 vs 135, 256->256@64 141 vs 143); the shallower layers are bound by staging and the epilogue, where
-  // the wider patch pitch costs more than the shape gains (128->128@128 164 vs 160, 128->64@256 382 vs 358)
-  static const char* const force = getenv("SEGK_PIPE_MFMA");  // A/B switch for tools/kbench.py: "16" or "32"
-  const bool m16 = force ? (force[0] == '1') : (a.CA + a.CB >= 256);
+  // 16x16x32 consumers on every layer of this kernel.  Round 2 kept the 32x32x16 form for Cin = 128 (same-box kbench: 128->128@128
+  // 164 vs 160 us); on the whole step the 16x16 form is 0.5 % faster on all three A/B pairs of round 3 (12.19 / 12.23 / 12.18 vs
+  // 12.22 / 12.28 / 12.28 ms), its producers' stores lose 6 % of their LDS cycles to bank conflicts instead of 22 %, and its
+  // build has no spilled registers (the 32x32 instances carry 45-60 outside the K loop).  The 32x32x16 form stays compiled
+  // for the A/B switch.
+  static const char* const force = getenv("SEGK_PIPE_MFMA");  // A/B switch for tools/kbench.py / tools/ab_bench.sh: "16" or "32"
+  const bool m16 = force ? (force[0] == '1') : true;
   return m16 ? launch_pipe_m<TWL, PRO, BN, true>(a, st) : launch_pipe_m<TWL, PRO, BN, false>(a, st);
 }
 
