@@ -172,6 +172,32 @@ def head():
     print(f"head fwd {tf:7.1f} us ({P*(2*C+4*ncls)/tf/1e3:7.1f} GB/s)   bwd {tb:7.1f} us ({P*(4*C+4*ncls)/tb/1e3:7.1f} GB/s)")
 
 
+def vit():
+    """The four GEMMs of a ViT-B/16 encoder layer at BASELINE config 4 (B = 16, 197 tokens: M = 3152 rows): QKV, out_proj
+    (K split three ways), fc1 (+ quick_gelu), fc2 (K split three ways), through the C ABI."""
+    dt = torch.bfloat16
+    M, D, I = 16 * 197, 768, 3072
+    Mp = (M + 15) // 16 * 16
+    st = ops._stream()
+    def packed(n, k):
+        w = torch.randn((n, k), device="cuda") / k ** 0.5
+        return ops.pack_conv(w.reshape(n, k, 1, 1), k, 0, dt, 0, taps=1)
+    nosplit = os.environ.get("KB_NOSPLIT") is not None      # with SEGK_GEMM_PIPE_MIN_CHUNKS=1000: the generic kernel, no split-K
+    for name, K, N, act, S in (("qkv", D, 3 * D, 0, 1), ("out_proj", D, D, 0, 3), ("fc1", D, I, 1, 1), ("fc2", I, D, 0, 3)):
+        S = 1 if nosplit else S
+        a = torch.randn((Mp, K), device="cuda").to(dt)
+        w = packed(N, K)
+        bias = torch.zeros(N, device="cuda")
+        o = torch.empty((S * Mp, N), dtype=dt, device="cuda")
+        if S > 1:
+            f = lambda: _lib.call("segk_linear_splitk", a.data_ptr(), w.data_ptr(), bias.data_ptr(), o.data_ptr(), Mp, K, N, S, 1, st)
+        else:
+            f = lambda: _lib.call("segk_linear", a.data_ptr(), w.data_ptr(), bias.data_ptr(), o.data_ptr(), Mp, K, N, act, 1, st)
+        t = timeit(f, 50)
+        fl = 2.0 * M * K * N
+        print(f"vit {name:9s} M={M} K={K:5d} N={N:5d} S={S}  {t:7.1f} us  {fl/t/1e6:7.1f} TF/s")
+
+
 def pack():
     """Weight re-layout after an optimizer step: one-pass forward + data-gradient pack against the two per-mode packs,
     all 18 Conv3x3 weights of the U-Net."""
@@ -189,6 +215,9 @@ def pack():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pack":
         pack()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "vit":
+        vit()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "head":
         head()
