@@ -175,6 +175,7 @@ class ClipUNet(_FusedBase):
         return self
 
     def forward(self, x):
-        ops.repack_stale(self)
+        ops.repack_stale(self)                   # after an optimizer step: the decoder's weight pairs re-packed by one launch
         x, skips = self.encoder(x)
-        return self.decoder(x, skips, head=self.output_layer)
+        with ops.defer_batch_counters():         # one fused update of the decoder's num_batches_tracked counters
+            return self.decoder(x, skips, head=self.output_layer)

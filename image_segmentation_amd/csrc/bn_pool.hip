@@ -605,13 +605,27 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
   float s[E::VEC];
 #pragma unroll
   for (int j = 0; j < E::VEC; ++j) s[j] = 0.f;
-  if (l.active && l.ry < rows)
-    for (long p = (long)blockIdx.x * rows + l.ry; p < P; p += (long)gridDim.x * rows) {
+  if (l.active && l.ry < rows) {
+    auto one = [&](const uint4 raw) {
       float f[E::VEC];
-      unpack16<T>(*(const uint4*)(x + (size_t)p * C + l.cv * E::VEC), f);
+      unpack16<T>(raw, f);
 #pragma unroll
       for (int j = 0; j < E::VEC; ++j) s[j] += f[j];
+    };
+    // a read-only pass on two blocks per CU: four pixels per thread in flight, consumed in the old order (bit-identical sums)
+    const long step = (long)gridDim.x * rows;
+    const size_t cofs = (size_t)l.cv * E::VEC;
+    long p = (long)blockIdx.x * rows + l.ry;
+    for (; p + 3 * step < P; p += 4 * step) {
+      uint4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = *(const uint4*)(x + (size_t)(p + u * step) * C + cofs);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(r[u]);
     }
+    for (; p < P; p += step) one(*(const uint4*)(x + (size_t)p * C + cofs));
+  }
   if (l.ry < rows) {
     float* r = red + ((size_t)l.ry * cvb + l.cx) * E::VEC;
 #pragma unroll
@@ -626,19 +640,32 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
       part[(size_t)blockIdx.x * C + l.cv * E::VEC + j] = a;
     }
 }
-__global__ __launch_bounds__(256) void channel_sum_finalize_kernel(const float* __restrict__ part, int NB, int C,
-                                                                   int C_real, float* out) {
-  __shared__ double sh[8][32];
+__global__ __launch_bounds__(1024) void channel_sum_finalize_kernel(const float* __restrict__ part, int NB, int C,
+                                                                    int C_real, float* out) {
+  // 32 channels x 32 row lanes, sixteen rows in flight per lane (unconditional loads of a clamped row): NB <= 512
+  // (segk_bn_bwd_blocks) is one memory round trip.  Fixed order of additions: bit-stable
+  __shared__ double sh[32][32];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   double s = 0.0;
-  if (c < C)
-    for (int b = ry; b < NB; b += 8) s += (double)part[(size_t)b * C + c];
+  if (c < C) {
+    for (int m = ry; m < NB; m += 512) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = m + 32 * u < NB ? m + 32 * u : NB - 1;
+        v[u] = part[(unsigned)r * (unsigned)C + (unsigned)c];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += (m + 32 * u < NB) ? (double)v[u] : 0.0;
+    }
+  }
   sh[ry][cx] = s;
   __syncthreads();
   if (ry != 0 || c >= C_real) return;
   s = 0.0;
-  for (int r = 0; r < 8; ++r) s += sh[r][cx];
+#pragma unroll 8
+  for (int r = 0; r < 32; ++r) s += sh[r][cx];
   out[c] = (float)s;
 }
 
@@ -877,7 +904,7 @@ int segk_channel_sum_impl(const void* x, long P, int C, int C_real, float* part,
   else
     hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(gx, gy), dim3(256), lds, st, (const float*)x, P, C, cvb, rows, part);
   SEGK_CHECK_LAUNCH("channel_sum");
-  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C / 32), dim3(256), 0, st, part, gx, C, C_real, out);
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C / 32), dim3(1024), 0, st, part, gx, C, C_real, out);
   SEGK_CHECK_LAUNCH("channel_sum_finalize");
   return 0;
 }

@@ -56,29 +56,35 @@ __device__ __forceinline__ int dual_map(int kp, int CA, int CAp, int CB, int CBp
 //  mode 0 (forward):   dst[kc][tap][n][j] = W[n][ci(kc*CH+j)][tap]                   K = input channels
 //  mode 1 (data grad): dst[kc][tap][n][j] = W[co = kc*CH+j][ci(n)][taps-1-tap]        K = output channels
 template <typename T>
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int CA, int CB,
-                                        int Coutp, int CAp, int CBp, int taps, int mode) {
+__device__ __forceinline__ T conv_packed_value(const float* __restrict__ w, long i, int Cout, int CA, int CB, int Coutp, int CAp,
+                                              int CBp, int taps, int mode) {
   constexpr int CH = ET<T>::CH;
   const int Cin = CA + CB, Cinp = CAp + CBp;
+  const int Np = mode == 0 ? Coutp : Cinp;
+  const int j = (int)(i % CH);
+  long r = i / CH;
+  const int n = (int)(r % Np); r /= Np;
+  const int tap = (int)(r % taps);
+  const int kc = (int)(r / taps);
+  const int k = kc * CH + j;
+  float v = 0.f;
+  if (mode == 0) {
+    const int ci = dual_map(k, CA, CAp, CB, CBp);
+    if (ci >= 0 && n < Cout) v = w[((long)n * Cin + ci) * taps + tap];
+  } else {
+    const int ci = dual_map(n, CA, CAp, CB, CBp);
+    if (ci >= 0 && k < Cout) v = w[((long)k * Cin + ci) * taps + (taps - 1 - tap)];
+  }
+  return from_float<T>(v);
+}
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int CA, int CB,
+                                        int Coutp, int CAp, int CBp, int taps, int mode) {
+  const int Cinp = CAp + CBp;
   const int Kp = mode == 0 ? Cinp : Coutp, Np = mode == 0 ? Coutp : Cinp;
   const long total = (long)Kp * taps * Np;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int j = (int)(i % CH);
-    long r = i / CH;
-    const int n = (int)(r % Np); r /= Np;
-    const int tap = (int)(r % taps);
-    const int kc = (int)(r / taps);
-    const int k = kc * CH + j;
-    float v = 0.f;
-    if (mode == 0) {
-      const int ci = dual_map(k, CA, CAp, CB, CBp);
-      if (ci >= 0 && n < Cout) v = w[((long)n * Cin + ci) * taps + tap];
-    } else {
-      const int ci = dual_map(n, CA, CAp, CB, CBp);
-      if (ci >= 0 && k < Cout) v = w[((long)k * Cin + ci) * taps + (taps - 1 - tap)];
-    }
-    dst[i] = from_float<T>(v);
-  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+    dst[i] = conv_packed_value<T>(w, i, Cout, CA, CB, Coutp, CAp, CBp, taps, mode);
 }
 
 // Both packed layouts of a 3x3 weight in ONE pass (they are re-made after every optimizer step: 35 + 8 packs per U-Net
@@ -187,9 +193,17 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const SegkPackEntry* __
       ((T*)t.dst_fwd)[i] = convt_packed_value<T>(t.w, i, t.CA, t.Cout, t.CAp, t.Coutp, 0);
       if (t.dst_dgrad) ((T*)t.dst_dgrad)[i] = convt_packed_value<T>(t.w, i, t.CA, t.Cout, t.CAp, t.Coutp, 1);
     }
-  } else {
+  } else if (t.kind == 3) {                        // Conv2d 1x1 weight [Cout][CA]: forward (and data-gradient) layout, taps = 1
+    const long total = (long)t.CAp * t.Coutp;
+    const long i0 = (long)lid * PACK_CONVT_CHUNK;
+    for (long i = i0 + threadIdx.x; i < i0 + PACK_CONVT_CHUNK && i < total; i += 256) {
+      ((T*)t.dst_fwd)[i] = conv_packed_value<T>(t.w, i, t.Cout, t.CA, 0, t.Coutp, t.CAp, 0, 1, 0);
+      if (t.dst_dgrad) ((T*)t.dst_dgrad)[i] = conv_packed_value<T>(t.w, i, t.Cout, t.CA, 0, t.Coutp, t.CAp, 0, 1, 1);
+    }
+  } else {                                         // kind 2: bias [Cout] -> fp32 [reps][Coutp], reps = CA (0 means 4)
     float* d = (float*)t.dst_fwd;
-    for (int i = threadIdx.x; i < 4 * t.Coutp; i += 256) {
+    const int reps = t.CA > 0 ? t.CA : 4;
+    for (int i = threadIdx.x; i < reps * t.Coutp; i += 256) {
       const int c = i % t.Coutp;
       d[i] = c < t.Cout ? t.w[c] : 0.f;
     }

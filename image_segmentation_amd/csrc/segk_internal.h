@@ -58,7 +58,8 @@ int segk_conv_twl(int bm, int W);         // log2 tile width
 // one tensor of segk_pack_multi's device table (64 bytes; the host builds it as 8 int64 words)
 //   kind 0: Conv2d 3x3 weight OIHW -> forward + data-gradient layouts   (blocks: (CAp+CBp)/32 * Coutp/32)
 //   kind 1: ConvTranspose2d(k=2,s=2) weight IOHW -> GEMM + un-shuffle layouts; CA = Cin, CAp = Cinp  (blocks: ceil(Cinp*4*Coutp / 2048))
-//   kind 2: ConvTranspose2d bias [Cout] -> fp32 [4][Coutp] (one block); dst_dgrad unused
+//   kind 2: bias [Cout] -> fp32 [reps][Coutp] (one block), reps = CA (0: 4, the ConvTranspose2d bias4 operand; 1: a conv bias); dst_dgrad unused
+//   kind 3: Conv2d 1x1 weight [Cout][CA] -> forward + data-gradient (may be null) layouts  (blocks: ceil(CAp*Coutp / 2048))
 struct SegkPackEntry {
   const float* w;       // fp32 parameter
   void* dst_fwd;        // forward layout

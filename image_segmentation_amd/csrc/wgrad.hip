@@ -284,7 +284,10 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, (sizeof(T) == 2 ?
 // accumulator oriented [co][ci]; the tap index mirrors (tap -> 8 - tap).
 // WC x WI waves of 32 x 32 blocks make the workgroup's (n, k) tile; 4 x 2 (eight waves, one workgroup per CU) moves
 // 0.7 of the LDS-DMA bytes per FLOP of two 2 x 2 workgroups: the deep layers are bound by that L2 -> LDS fill rate.
-template <int WC, int WI, bool PRO>
+// RAG: the image is not whole 8 x 16 tiles (H % 8 or W % 16 != 0: the 14 / 28 / 56-pixel levels of the CLIP decoder): a piece's
+// pixel is then tested against the tile's valid rows / columns (two compares more per piece) instead of the four
+// "this side of the patch is outside" bits, and pixels of the tile beyond the image read the zero page like halo pixels do.
+template <int WC, int WI, bool PRO, bool RAG>
 __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma_kernel(const WgradArgs a) {
   typedef bf16_t T;
   constexpr int NWV = WC * WI > 4 ? WC * WI : 4;          // waves per workgroup
@@ -322,10 +325,11 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
   // patch region's unused tail).  Per tile the address of a piece is then scalar tile base + poff, and a lane reads the zero
   // page instead when its flags meet the tile's "this side is outside the image" bits: ~8 vector instructions per piece
   // where a general form (any tile may cross the image edge) spends ~40 on
-  // divisions, bounds tests and 64-bit multiplies, issued by all eight waves in front of every tile's MFMAs (the general
-  // form lives on in wgrad_kernel, which serves images that are not whole 8 x 16 tiles).
+  // divisions, bounds tests and 64-bit multiplies, issued by all eight waves in front of every tile's MFMAs (the RAG
+  // instances add two compares per piece for images that are not whole 8 x 16 tiles).
   constexpr int NI = (NINSTR + NWV - 1) / NWV;
   int poff[NI];
+  int pyx[RAG ? NI : 1];                                  // RAG: (patch row << 8) | patch column of the lane's pixel (U: r+1, lp+1)
   unsigned pflag[(NI + 5) / 6];
 #pragma unroll
   for (int q = 0; q < (NI + 5) / 6; ++q) pflag[q] = 0u;
@@ -335,6 +339,7 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
     if (j < WU * 8) {
       const int blk = j >> 3, r = j & 7;
       poff[i] = ((r * W + lp) * UC + blk * 32 + lc * 8) * 2;
+      if constexpr (RAG) pyx[i] = ((r + 1) << 8) | (lp + 1);
     } else {
       const int jj = j - WU * 8;
       const int blk = jj / 12, ch = jj - blk * 12;
@@ -344,6 +349,7 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
       const unsigned f = (py == 0 ? 1u : 0u) | (py == 9 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == 17 ? 8u : 0u) |
                          (pp >= 180 ? 16u : 0u);
       pflag[i / 6] |= f << (5 * (i % 6));
+      if constexpr (RAG) pyx[i] = (py << 8) | px;
     }
   }
   auto issue_tile = [&](int t, int bufsel) {
@@ -366,7 +372,14 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
         char* const dst = is_u ? bb + (j >> 3) * (NU * BLKP) + (j & 7) * 1024
                                : bb + UB + (jj / 12) * (NV * BLKP) + (jj % 12) * 1024;
         const char* const base = is_u ? ub0 : vb0;
-        const bool bad = ((pflag[i / 6] >> (5 * (i % 6))) & out) != 0u;
+        bool bad;
+        if constexpr (RAG) {                               // rows y0 + py - 1 and columns x0 + px - 1 against the image
+          const int py = pyx[i] >> 8, px = pyx[i] & 255;
+          bad = (((pflag[i / 6] >> (5 * (i % 6))) & 16u) != 0u) | (py == 0 ? y0 == 0 : py > H - y0) |
+                (px == 0 ? x0 == 0 : px > W - x0);
+        } else {
+          bad = ((pflag[i / 6] >> (5 * (i % 6))) & out) != 0u;
+        }
         const char* const src = bad ? zsrc : base + (ptrdiff_t)poff[i];
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -544,13 +557,13 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
   }
 }
 
-template <int WC, int WI, bool PRO>
+template <int WC, int WI, bool PRO, bool RAG>
 int launch_dma(const WgradArgs& a, hipStream_t st) {
   constexpr int WU = PRO ? WI : WC, WV = PRO ? WC : WI;
   constexpr size_t lds = 2 * ((size_t)WU * 128 * 64 + (size_t)WV * 192 * 64);
   static_assert(lds <= 160 * 1024, "wgrad_dma: LDS exceeds 160 KiB");
   const int NCT = (a.CD / (32 * WC)) * ((a.CA + a.CB) / (32 * WI));
-  auto kern = wgrad_dma_kernel<WC, WI, PRO>;
+  auto kern = wgrad_dma_kernel<WC, WI, PRO, RAG>;
   static bool attr_set[SEGK_MAX_DEVICES] = {};     // per device: the attribute is device state
   const int dev_ = segk_device_index();
   if (!attr_set[dev_]) {
@@ -565,7 +578,9 @@ int launch_dma(const WgradArgs& a, hipStream_t st) {
 
 template <int WC, int WI>
 int launch_dma_pro(const WgradArgs& a, hipStream_t st) {
-  return a.scale ? launch_dma<WC, WI, true>(a, st) : launch_dma<WC, WI, false>(a, st);
+  const bool rag = a.H % 8 != 0 || a.W % 16 != 0;       // images that are not whole 8 x 16 tiles
+  if (rag) return a.scale ? launch_dma<WC, WI, true, true>(a, st) : launch_dma<WC, WI, false, true>(a, st);
+  return a.scale ? launch_dma<WC, WI, true, false>(a, st) : launch_dma<WC, WI, false, false>(a, st);
 }
 
 template <typename T, int GEO, int WC, int WI>
@@ -591,9 +606,8 @@ int launch_geo(const WgradArgs& a, hipStream_t st) {
   const bool wc2 = a.CD % 64 == 0;
   const bool wi2 = a.CA % 64 == 0 && a.CB % 64 == 0;
   if constexpr (GEO == 0 && sizeof(T) == 2) {
-    // bf16 3x3: LDS-DMA kernel (needs the caller's zero page).  Its tile walk assumes whole 8 x 16 tiles (every U-Net /
-    // CLIP-decoder level: H % 8 == 0 and W % 16 == 0); other image sizes take the register-staged kernel below
-    if (a.zeros && a.H % 8 == 0 && a.W % 16 == 0) {
+    // bf16 3x3: LDS-DMA kernel (needs the caller's zero page); images that are not whole 8 x 16 tiles take its RAG instances
+    if (a.zeros) {
       if (segk_wgrad_wc(a.CD, a.CA, a.CB, 0, SEGK_DT_BF16) == 4) return launch_dma_pro<4, 2>(a, st);
       if (wc2 && wi2) return launch_dma_pro<2, 2>(a, st);
       if (wc2) return launch_dma_pro<2, 1>(a, st);

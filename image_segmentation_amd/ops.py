@@ -239,8 +239,35 @@ def _entry_geometry(kind, param, d0, d1):
             _PACK_CONVT_CHUNK[0] = _lib.query("segk_pack_convt_chunk")
         n = Cinp * 4 * Coutp
         return n, (Cout, Cin, 0, Coutp, Cinp, 0), (n + _PACK_CONVT_CHUNK[0] - 1) // _PACK_CONVT_CHUNK[0]
-    Cout = param.shape[0]    # kind 2: ConvTranspose2d bias -> fp32 [4][Coutp]
-    return 4 * pad32(Cout), (Cout, 0, 0, pad32(Cout), 0, 0), 1
+    if kind == 3:            # Conv2d 1x1 weight [Cout][Cin][1][1]: d0 = Cin (forward layout only: key_b is None)
+        Cout = param.shape[0]
+        Coutp, CAp = pad32(Cout), pad32(d0)
+        if not _PACK_CONVT_CHUNK[0]:
+            _PACK_CONVT_CHUNK[0] = _lib.query("segk_pack_convt_chunk")
+        n = CAp * Coutp
+        return n, (Cout, d0, 0, Coutp, CAp, 0), (n + _PACK_CONVT_CHUNK[0] - 1) // _PACK_CONVT_CHUNK[0]
+    Cout = param.shape[0]    # kind 2: bias -> fp32 [reps][Coutp]; d0 = reps (0: the 4 of a ConvTranspose2d bias, 1: a conv bias)
+    reps = d0 if d0 > 0 else 4
+    return reps * pad32(Cout), (Cout, d0, 0, pad32(Cout), 0, 0), 1
+
+
+def _pack_caches(model):
+    """Every PackCache under `model`: registered sub-modules and the fused drivers a module keeps OUT of the module tree
+    (object.__setattr__: the CLIP decoder's `_dc` / `_skip` / `_init`, which share their parameters with registered
+    children) -- without the second kind the decoder's weights were re-packed by one launch each."""
+    seen, out, stack = set(), [], list(model.modules())
+    while stack:
+        m = stack.pop()
+        if id(m) in seen:
+            continue
+        seen.add(id(m))
+        c = getattr(m, "cache", None)
+        if isinstance(c, PackCache):
+            out.append(c)
+        for v in vars(m).values():
+            if isinstance(v, torch.nn.Module) and id(v) not in seen:
+                stack.extend(v.modules())
+    return out
 
 
 def repack_stale(model):
@@ -257,7 +284,7 @@ def repack_stale(model):
         return
     st["epoch"] = _OPT_EPOCH[0]
     if st["caches"] is None:
-        st["caches"] = [m.cache for m in model.modules() if isinstance(getattr(m, "cache", None), PackCache)]
+        st["caches"] = _pack_caches(model)
     groups = {}
     for cache in st["caches"]:
         for key_a, (kind, key_b, param, d0, d1, dtype) in cache.multi.items():
@@ -1165,13 +1192,14 @@ class Conv1x1Fn(torch.autograd.Function):
         Cout = w.shape[0]
         Cinp, Coutp = pad32(Cin), pad32(Cout)
         x_t, px, _ = _raw(x, dtype)
-        wp = mod.cache.get(("cf", dtype), w, lambda: pack_conv(w, Cin, 0, dtype, 0, taps=1))
+        # both operands are registered for the model's one-launch re-pack after an optimizer step (repack_stale)
+        wp = mod.cache.get_registered(("cf", dtype), w, lambda: pack_conv(w, Cin, 0, dtype, 0, taps=1), meta=(3, Cin, 0, dtype))
 
         def biasp():
             t = torch.zeros((Coutp,), dtype=torch.float32, device=dev)
             t[:Cout] = _param_f32(b)
             return t
-        bp = None if b is None else mod.cache.get(("cb", dtype), b, biasp)
+        bp = None if b is None else mod.cache.get_registered(("cb", dtype), b, biasp, meta=(2, 1, 0, dtype))
         out = torch.empty((B, H, W, Coutp), dtype=dtype, device=dev)
         _lib.call("segk_conv1x1", px, wp.data_ptr(), _p(bp), out.data_ptr(), B, H, W, Cinp, Coutp, _DT[dtype], _stream())
         ctx.mod, ctx.dtype, ctx.dims = mod, dtype, (B, H, W, Cin, Cout)

@@ -64,7 +64,10 @@ int segk_pack_conv3x3_both(const float* w, void* dst_fwd, void* dst_dgrad, int C
  *   kind 0: segk_pack_conv3x3_both (blocks (CAp+CBp)/32 * Coutp/32);
  *   kind 1: segk_pack_convt_weight, mode 0 into dst_fwd and mode 1 into dst_dgrad (may be NULL), CA = Cin, CAp = Cinp
  *           (blocks ceil(Cinp*4*Coutp / segk_pack_convt_chunk()));
- *   kind 2: ConvTranspose2d bias w [Cout] -> dst_fwd fp32 [4][Coutp], the bias4 operand of segk_convt2x2_fwd (1 block). */
+ *   kind 2: bias w [Cout] -> dst_fwd fp32 [reps][Coutp] (1 block), reps = CA, 0 meaning 4: the bias4 operand of
+ *           segk_convt2x2_fwd; reps 1: the padded bias operand of segk_conv1x1;
+ *   kind 3: Conv2d 1x1 weight w [Cout][CA] -> segk_pack_conv_weight(taps 1) mode 0 into dst_fwd and mode 1 into dst_dgrad
+ *           (may be NULL) (blocks ceil(CAp*Coutp / segk_pack_convt_chunk())). */
 int segk_pack_multi(const void* table, int n, int total_blocks, int dtype, segk_stream_t s);
 int segk_pack_convt_chunk(void);
 /* ConvTranspose2d(k=2,s=2) weight IOHW fp32 [Cin][Cout][2][2] -> MFMA layout; mode 0 forward, 1 data-gradient */

@@ -123,3 +123,59 @@ def test_clipunet_end_to_end_vs_oracle(seg):
     keys = list(m.state_dict().keys())
     assert "decoder.decoder_blocks.0.conv_block.0.weight" in keys and "output_layer.bias" in keys
     assert any(k.startswith("encoder.clip_vit.") for k in keys)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_clip_decoder_one_launch_repack_after_optimizer_step(seg, dtype):
+    """ops.repack_stale on the CLIP decoder: its fused drivers (`_dc`, `_skip`, `_init`) live outside the module tree, so the
+    cache walk has to find them; after an optimizer step every registered copy -- 8 3x3 weight pairs, 4 ConvTranspose pairs and
+    bias operands, and the 5 1x1 convs' forward weights (kind 3) and padded biases (kind 2, one repeat) -- equals a fresh
+    per-tensor pack of the stepped parameter bit for bit, in the buffers that were there before."""
+    from image_segmentation_amd import ops
+    seg.set_compute_dtype(dtype)
+    dec = seg.UNetDecoder(64, [64, 32, 32, 32, 32]); head = torch.nn.Conv2d(32, 4, 1)
+
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.decoder, self.output_layer = dec, head
+
+        def forward(self, x, skips):
+            ops.repack_stale(self)
+            return self.decoder(x, skips, head=self.output_layer)
+    m = Wrap(); fill_module(m, 4100); m.cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, fused=True)
+    x = fill((2, 64, 4, 4), 11, -1, 1).cuda()
+    skips = [fill((2, 64, 4, 4), 20 + i, -1, 1).cuda() for i in range(4)]
+    Y = labels((2, 64, 64), 3, 4).cuda()
+    loss_fn = seg.CrossEntropyLoss()
+    loss_fn(m(x, skips), Y).backward(); opt.step(); opt.zero_grad(set_to_none=True)
+    caches = ops._pack_caches(m)
+    entries = [(c, ka) for c in caches for ka in c.multi]
+    kinds = sorted(c.multi[ka][0] for c, ka in entries)
+    assert kinds == [0] * 8 + [1] * 4 + [2] * 9 + [3] * 5, kinds
+    before = {id(c._c[ka][1]): c._c[ka][1].clone() for c, ka in entries}
+    ptrs = {(id(c), ka): c._c[ka][1].data_ptr() for c, ka in entries}
+    ops.repack_stale(m)
+    for c, ka in entries:
+        kind, kb, param, d0, d1, dt = c.multi[ka]
+        ver = (param._version, param.data_ptr(), param.device, ops._OPT_EPOCH[0])
+        assert c._c[ka][0] == ver and (kb is None or c._c[kb][0] == ver), ka
+        assert c._c[ka][1].data_ptr() == ptrs[(id(c), ka)]
+        d = None
+        if kind == 0:
+            f, d = ops.pack_conv_both(param, d0, d1, dt)
+        elif kind == 1:
+            f, d = ops.pack_convt(param, dt, 0), ops.pack_convt(param, dt, 1)
+        elif kind == 3:
+            f = ops.pack_conv(param, d0, 0, dt, 0, taps=1)
+        else:
+            reps = d0 if d0 > 0 else 4
+            f = torch.zeros((reps, c._c[ka][1].numel() // reps), device="cuda"); f[:, :param.shape[0]] = param.detach()
+        assert torch.equal(c._c[ka][1].view_as(f), f), (kind, ka)
+        if d is not None:
+            assert torch.equal(c._c[kb][1], d), (kind, kb)
+        assert not torch.equal(c._c[ka][1], before[id(c._c[ka][1])]), (kind, ka)      # the step really moved it
+    l2 = loss_fn(m(x, skips), Y); l2.backward()
+    assert torch.isfinite(l2)
+    seg.set_compute_dtype(torch.bfloat16)

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--model", default="unet", choices=["unet", "clipunet"])
     args = ap.parse_args()
     import torch
     from torch.profiler import profile, ProfilerActivity
@@ -24,11 +25,16 @@ def main():
     dev = torch.device("cuda", 0)
     seg.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(1234)
-    model = seg.unet(3, 3).to(dev).train()
-    opt = torch.optim.AdamW(model.parameters(), weight_decay=0.01, fused=True)
+    ncls = 3
+    if args.model == "clipunet":
+        ncls = 4
+        model = seg.ClipUNet(num_classes=4, encoder=seg.ClipViTEncoder.from_config()).to(dev).train()
+    else:
+        model = seg.unet(3, 3).to(dev).train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], weight_decay=0.01, fused=True)
     loss_fn = seg.CrossEntropyLoss()
     X = bench.fill((args.batch, 3, args.size, args.size), 1, 0, 1).to(dev)
-    Y = bench.labels((args.batch, args.size, args.size), 2, 3).to(dev)
+    Y = bench.labels((args.batch, args.size, args.size), 2, ncls).to(dev)
 
     def step():
         opt.zero_grad(set_to_none=True)
