@@ -65,16 +65,16 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 4) void stem_stream_kernel(const f
     wf[g] = (u32x4){pk_bf16(f[0], f[1]), pk_bf16(f[2], f[3]), pk_bf16(f[4], f[5]), pk_bf16(f[6], f[7])};
   }
   // ---- the lane's eight (channel, tap) gathers: offset from the pixel's own element of channel 0, and (dy, dx)
-  int goff[8], gdy[8], gdx[8];
-  unsigned kmask = 0;                              // bit e: k = 8 lq + e is a real (channel, tap), not K padding
+  // 8 bits per gather e (four per register): (dy + 1) | (dx + 1) << 2 | ci << 4 | real << 6 -- the offset ci * HW + dy * W + dx is
+  // rebuilt per block from these (two multiply-adds) instead of living in eight registers beside two blocks of gathers
+  unsigned gpk[2] = {0u, 0u};
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int k = lq * 8 + e;
     const int ci = k / 9, tap = k - ci * 9;
-    kmask |= (k < K ? 1u : 0u) << e;
-    gdy[e] = tap / 3 - 1;
-    gdx[e] = tap % 3 - 1;
-    goff[e] = k < K ? (int)(ci * HW) + gdy[e] * W + gdx[e] : 0;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const unsigned bits = k < K ? (unsigned)((dy + 1) | ((dx + 1) << 2) | (ci << 4) | (1 << 6)) : 0x05u;   // padding: dy = dx = 0
+    gpk[e >> 2] |= bits << (8 * (e & 3));
   }
 
   float s1[2][8], s2[2][8];
@@ -84,30 +84,44 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 4) void stem_stream_kernel(const f
     for (int j = 0; j < 8; ++j) { s1[p][j] = 0.f; s2[p][j] = 0.f; }
 
   const int W16 = W / 16;
-  // 32-bit block arithmetic (nblk < 2^31 by the launcher's shape check): a 64-bit division is a ~130-instruction loop
+  // 32-bit block arithmetic (nblk < 2^31 by the launcher's shape check): a 64-bit division is a ~130-instruction loop.
+  // The loop is bound by the latency of its gathers (16 waves per CU, one memory round trip per 16-pixel block and wave): two
+  // blocks are fetched per pass.  A register set holds the raw gathers (from an address clamped to the pixel itself where the
+  // tap lies outside the image) and the validity bits that zero them when the block is consumed -- a select at fetch time
+  // would wait for the loads right there.
   const unsigned step = gridDim.x * STEM_WAVES;
-  for (unsigned blk = blockIdx.x * STEM_WAVES + wave; blk < (unsigned)nblk; blk += step) {
-    const unsigned row = blk / (unsigned)W16;      // b * H + y
-    const int xx = (int)(blk - row * W16) * 16 + lc;
-    const unsigned b = row / (unsigned)H;
-    const int y = (int)(row - b * H);
-    const float* px = x + (size_t)b * Cin * HW + (size_t)y * W + xx;
-    float v[8];
+  struct Blk { unsigned row; int xx; unsigned ok; float g[8]; };
+  auto fetch = [&](unsigned blk, Blk& k) {
+    k.row = blk / (unsigned)W16;                   // b * H + y
+    k.xx = (int)(blk - k.row * W16) * 16 + lc;
+    const unsigned b = k.row / (unsigned)H;
+    const int y = (int)(k.row - b * H);
+    // 32-bit element index off the uniform base pointer (one address register per gather instead of two; the launcher's
+    // shape check keeps B * Cin * H * W below 2^31)
+    const unsigned base = (b * (unsigned)Cin) * (unsigned)HW + (unsigned)y * (unsigned)W + (unsigned)k.xx;
+    unsigned ok = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const bool ok = ((kmask >> e) & 1u) & ((unsigned)(y + gdy[e]) < (unsigned)H) & ((unsigned)(xx + gdx[e]) < (unsigned)W);
-      const float g = px[ok ? goff[e] : 0];        // unconditional (a conditional load compiles to branch + load + wait)
-      v[e] = ok ? g : 0.f;
+      const unsigned bits = gpk[e >> 2] >> (8 * (e & 3));
+      const int dy = (int)(bits & 3u) - 1, dx = (int)((bits >> 2) & 3u) - 1, ci = (int)((bits >> 4) & 3u);
+      const bool v = ((bits >> 6) & 1u) & ((unsigned)(y + dy) < (unsigned)H) & ((unsigned)(k.xx + dx) < (unsigned)W);
+      ok |= (v ? 1u : 0u) << e;
+      const int off = ci * (int)HW + dy * W + dx;
+      k.g[e] = x[base + (unsigned)(v ? off : 0)];   // unconditional (a conditional load compiles to branch + load + wait)
     }
-    float c0 = 0.f, c1r = 0.f, c2r = 0.f;          // side output: the pixel's own channels, fetched with the gathers
-    if (xn != nullptr) { c0 = px[0]; c1r = px[Cin > 1 ? HW : 0]; c2r = px[Cin > 2 ? 2 * HW : 0]; }
+    k.ok = ok;
+  };
+  auto work = [&](const Blk& k) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ((k.ok >> e) & 1u) ? k.g[e] : 0.f;
     const u32x4 bf = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[g]), __builtin_bit_cast(bf16x8, bf),
                                                        (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    const size_t opix = (size_t)row * W + xx;
+    const size_t opix = (size_t)k.row * W + k.xx;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const f32x4 a0 = acc[2 * p], a1 = acc[2 * p + 1];
@@ -117,13 +131,31 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 4) void stem_stream_kernel(const f
       const u32x4 ov = {pk_bf16(o[0], o[1]), pk_bf16(o[2], o[3]), pk_bf16(o[4], o[5]), pk_bf16(o[6], o[7])};
       *(u32x4*)(z + opix * 64 + p * 32 + lq * 8) = ov;
     }
-    if (xn != nullptr) {                           // padded NHWC copy of the input (32 channels: Cin real, zeros behind)
-      u32x4 c = {0u, 0u, 0u, 0u};
+    if (xn != nullptr) {                           // padded NHWC copy of the input (32 channels: Cin real, zeros behind);
+      u32x4 c = {0u, 0u, 0u, 0u};                  // not the training path (the weight gradient gathers from NCHW itself)
       if (lq == 0) {
-        c.x = pk_bf16(c0, Cin > 1 ? c1r : 0.f);
-        c.y = pk_bf16(Cin > 2 ? c2r : 0.f, 0.f);
+        const unsigned b = k.row / (unsigned)H;
+        const float* px = x + (size_t)b * Cin * HW + (size_t)(k.row - b * H) * W + k.xx;
+        const float c0 = px[0], c1 = Cin > 1 ? px[HW] : 0.f, c2 = Cin > 2 ? px[2 * HW] : 0.f;
+        c.x = pk_bf16(c0, c1);
+        c.y = pk_bf16(c2, 0.f);
       }
       *(u32x4*)(xn + opix * 32 + lq * 8) = c;
+    }
+  };
+  {
+    // two blocks per pass: both blocks' gathers are issued before either is consumed (one memory round trip for 32 pixels);
+    // blocks are consumed in index order, so the statistics add up in the old order, bit-identical
+    const unsigned nb = (unsigned)nblk;
+    unsigned blk = blockIdx.x * STEM_WAVES + wave;
+    for (; blk < nb; blk += 2 * step) {
+      const bool two = blk + step < nb;             // (wave-uniform) an odd last block is fetched twice, multiplied once
+      Blk ka, kb;
+      fetch(blk, ka);
+      fetch(two ? blk + step : blk, kb);
+      __builtin_amdgcn_sched_barrier(0);
+      work(ka);
+      if (two) work(kb);
     }
   }
   if (stats == nullptr) return;
@@ -187,11 +219,11 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_wgrad_kernel(const fl
     for (int r = 0; r < 16; ++r) acc[nh][r] = 0.f;
 
   const int W16 = W / 16;
-  const unsigned step = gridDim.x * STEM_WAVES;    // 32-bit block arithmetic, see stem_stream_kernel
-  for (unsigned blk = blockIdx.x * STEM_WAVES + wave; blk < (unsigned)nblk; blk += step) {
-    const unsigned row = blk / (unsigned)W16;      // b * H + y
+  const long step = (long)gridDim.x * STEM_WAVES;
+  for (long blk = (long)blockIdx.x * STEM_WAVES + wave; blk < nblk; blk += step) {
+    const long row = blk / W16;                    // b * H + y
     const int x0 = (int)(blk - row * W16) * 16;
-    const unsigned b = row / (unsigned)H;
+    const long b = row / H;
     const int y = (int)(row - b * H);
     // ---- dz: 16 pixels x 64 channels -> LDS, natural [block][pixel][64 B]
     const bf16_t* dp = dz + ((size_t)row * W + x0 + lp) * 64 + lc4 * 8;
@@ -206,15 +238,8 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_wgrad_kernel(const fl
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = a.v[e]; v[4 + e] = c.v[e]; }
     } else {
-      // image border: unconditional loads from the row / column clamped into the image, selected afterwards (eight
-      // conditional loads compile to eight serial round trips)
-      const int yc = y + dy < 0 ? 0 : (y + dy >= H ? H - 1 : y + dy);
-      const float* rowp = x + ((size_t)(b * Cin + (jok ? ci : 0)) * H + yc) * W;
-      float g[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const int xc = xs + e < 0 ? 0 : (xs + e >= W ? W - 1 : xs + e); g[e] = rowp[xc]; }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (rok && (unsigned)(xs + e) < (unsigned)W) ? g[e] : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = (rok && (unsigned)(xs + e) < (unsigned)W) ? src[e] : 0.f;
     }
     *(uint4*)(slot + lp * 64 + lc4 * 16) = d0;
     *(uint4*)(slot + 1024 + lp * 64 + lc4 * 16) = d1;
@@ -305,7 +330,7 @@ int segk_stem_wgrad_launch(const float* x, const void* dz, float* slabs, int B, 
 int segk_stem_rows(int B, int H, int W, int Cin, int Cout, int dtype) {
   static const bool off = getenv("SEGK_NO_STEM") != nullptr;            // A/B switch
   if (off || dtype != SEGK_DT_BF16 || B <= 0 || H <= 0 || W <= 0 || W % 16 != 0 || Cin < 1 || Cin > 3 || Cout != 64) return 0;
-  if ((long long)B * H * W * 64 >= 2147483647LL * 16 || (long long)Cin * H * W >= 2147483647LL) return 0;
+  if ((long long)B * H * W * 64 >= 2147483647LL * 16 || (long long)B * Cin * H * W >= 2147483647LL) return 0;
   const long nblk = (long)B * H * (W / 16);
   long g = (nblk + STEM_WAVES - 1) / STEM_WAVES;
   const long cap = (long)segk_num_cus() * STEM_WG_PER_CU;   // 8-wave workgroups per CU: the gathers want many in flight

@@ -198,6 +198,25 @@ def vit():
         print(f"vit {name:9s} M={M} K={K:5d} N={N:5d} S={S}  {t:7.1f} us  {fl/t/1e6:7.1f} TF/s")
 
 
+def stem():
+    """The U-Net stem (3 -> 64 @ 256 x 256 from the NCHW fp32 batch, B = 32): forward with statistics, and weight gradient."""
+    B, Cin, Cout, H, W = 32, 3, 64, 256, 256
+    x = torch.rand((B, Cin, H, W), device="cuda")
+    w = torch.randn((Cout, Cin, 3, 3), device="cuda") / 5
+    z = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device="cuda")
+    dz = torch.randn((B, H, W, Cout), device="cuda").to(torch.bfloat16)
+    rows = _lib.query("segk_stem3x3_rows", B, H, W, Cin, Cout, 1)
+    stats = torch.empty(_lib.query("segk_bn_stats_floats", rows, Cout), device="cuda")
+    S = _lib.query("segk_stem3x3_wgrad_slabs", B, H, W, Cin, Cout, 1)
+    slabs = torch.empty(S * 64 * 32, device="cuda")
+    st = ops._stream()
+    tf = timeit(lambda: _lib.call("segk_stem3x3", x.data_ptr(), w.data_ptr(), z.data_ptr(), 0, stats.data_ptr(), B, H, W, Cin,
+                                  Cout, 1, st), 30)
+    tw = timeit(lambda: _lib.call("segk_stem3x3_wgrad", x.data_ptr(), dz.data_ptr(), slabs.data_ptr(), B, H, W, Cin, Cout, 1, st), 30)
+    P = B * H * W
+    print(f"stem fwd {tf:7.1f} us ({P*(Cin*4+Cout*2)/tf/1e3:7.1f} GB/s)   wgrad {tw:7.1f} us ({P*(Cin*4+Cout*2)/tw/1e3:7.1f} GB/s)")
+
+
 def pack():
     """Weight re-layout after an optimizer step: one-pass forward + data-gradient pack against the two per-mode packs,
     all 18 Conv3x3 weights of the U-Net."""
@@ -215,6 +234,9 @@ def pack():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pack":
         pack()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stem":
+        stem()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "vit":
         vit()
