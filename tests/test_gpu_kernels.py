@@ -232,7 +232,10 @@ def test_conv3x3_dgrad_weights(ops, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 32, 32, 16, 16, 0), (1, 64, 128, 24, 40, 0), (2, 3, 64, 20, 20, 0),
-                                  (3, 96, 64, 14, 14, 0), (2, 40, 32, 9, 21, 72)])
+                                  (3, 96, 64, 14, 14, 0), (2, 40, 32, 9, 21, 72),
+                                  # images that are not whole 8 x 16 tiles on every LDS-DMA configuration (RAG instances): smaller
+                                  # than one tile, the 4 x 2-wave workgroup (CD % 128 == 0), and the CLIP decoder's 28 / 56 levels
+                                  (2, 32, 32, 5, 7, 0), (1, 128, 128, 28, 28, 0), (1, 64, 128, 56, 56, 64), (2, 64, 64, 8, 17, 0)])
 def test_wgrad_conv3x3(ops, dtype, case):
     B, Cin, Cout, H, W, CB = case
     x = fill((B, Cin, H, W), 1, -1, 1); g = fill((B, Cout, H, W), 2, -1, 1)
