@@ -242,3 +242,22 @@ def test_clip_encoder_loads_both_transformers_key_layouts():
     dst = seg.ClipUNet(num_classes=4, decoder_channels=[64, 32], encoder=seg.ClipViTEncoder.from_config(cfg, skip_indices=[1]))
     if own[:-1] + ".embeddings.position_ids" not in dst.state_dict() and own + "embeddings.position_ids" not in dst.state_dict():
         dst.load_state_dict(old, strict=True)
+
+
+def test_pack_caches_reach_the_fused_drivers_outside_the_module_tree():
+    """ops._pack_caches (what repack_stale refreshes in one launch): the CLIP decoder keeps its fused drivers (`_dc`, `_skip`,
+    `_init`) out of the module tree so that the state_dict keeps the reference's names; their caches must be found all the
+    same (round 3: they were not, and every decoder weight was re-packed by a launch of its own)."""
+    import image_segmentation_amd as seg
+    from image_segmentation_amd import ops
+    dec = seg.UNetDecoder(64, [64, 32, 32, 32, 32])
+    caches = ops._pack_caches(dec)
+    assert len(caches) == len({id(c) for c in caches})
+    want = {id(dec.cache), id(dec._init.cache)}
+    for blk in dec.decoder_blocks:
+        want |= {id(blk.cache), id(blk._dc.cache), id(blk._skip.cache)}
+    assert want <= {id(c) for c in caches}, (len(want), len(caches))
+    # a plain U-Net: every registered DoubleConv / Up / Down module, nothing twice
+    m = seg.unet(3, 3)
+    cu = ops._pack_caches(m)
+    assert len(cu) == len({id(c) for c in cu}) == sum(1 for x in m.modules() if isinstance(getattr(x, "cache", None), ops.PackCache))
