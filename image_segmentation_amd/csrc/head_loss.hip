@@ -115,6 +115,35 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
 // live in registers) and walks pixels; a row of threads covers whole contiguous pixel rows of y / dy.
 // ZIN: `y` holds the pre-activation z of the last DoubleConv block: y = relu(z * scale + shift) is re-formed per value
 // (rounded to T like the stored tensor would be) and the BatchNorm reductions take xhat = (z - mean) * rstd from z itself.
+// Vector width of the head's backward pass.  bf16 threads own FOUR channels (an 8-byte vector) instead of the eight of a
+// 16-byte one: the per-thread weight / gradient / BatchNorm arrays halve (176 -> ~100 registers), twice the waves fit a CU, and
+// the pass -- whose arithmetic (~73 us) and traffic (~100 us) added up at 8 waves per CU -- overlaps them.
+#ifndef HEAD_BWD_VEC
+#define HEAD_BWD_VEC 4
+#endif
+template <typename T> struct HeadVec;
+template <> struct HeadVec<float> {
+  static constexpr int HV = 4;
+  using Raw = uint4;
+  static __device__ __forceinline__ void unpack(const Raw& v, float* f) { unpack16<float>(v, f); }
+  static __device__ __forceinline__ Raw pack(const float* f) { return pack16<float>(f); }
+};
+template <> struct HeadVec<bf16_t> {
+  static constexpr int HV = HEAD_BWD_VEC;
+  static_assert(HV == 4 || HV == 8, "head backward: 4 or 8 bf16 channels per thread");
+  using Raw = std::conditional_t<HV == 8, uint4, uint2>;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* f) { unpack16<bf16_t>(v, f); }
+  static __device__ __forceinline__ void unpack(const uint2& v, float* f) {
+    f[0] = bf2f(v.x & 0xffffu); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = bf2f(v.y & 0xffffu); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ uint4 pack_n(const float* f, std::integral_constant<int, 8>) { return pack16<bf16_t>(f); }
+  static __device__ __forceinline__ uint2 pack_n(const float* f, std::integral_constant<int, 4>) {
+    return make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+  }
+  static __device__ __forceinline__ Raw pack(const float* f) { return pack_n(f, std::integral_constant<int, HV>{}); }
+};
+
 template <typename T, int NC, bool ZIN>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlog, const T* __restrict__ y,
                                                        const float* __restrict__ w, T* __restrict__ dy,
@@ -122,36 +151,37 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        int ncls, int cvb, int rows, const float* __restrict__ bn_scale,
                                                        const float* __restrict__ bn_shift, const float* __restrict__ bn_mean,
                                                        const float* __restrict__ bn_rstd, float* __restrict__ bnpart) {
-  using E = ET<T>;
+  constexpr int HV = HeadVec<T>::HV;                   // channels per thread (bf16: 4 = an 8-byte vector)
+  using Raw = typename HeadVec<T>::Raw;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;                       // [rows][cvb][MAXC*VEC + MAXC]
   // bnpart != NULL: y is the output relu(bn(z)) of the last DoubleConv block and dy its complete gradient: also accumulate
   // that BatchNorm's backward reductions sum(g), sum(g*xhat) (xhat recovered from y where the ReLU is active), like
   // maxpool_bwd_kernel<STAT> does for the Down blocks
   const bool stat = bnpart != nullptr;
-  float xa[E::VEC], xb[E::VEC], sg[E::VEC], sgx[E::VEC];
+  float xa[HV], xb[HV], sg[HV], sgx[HV];
 #pragma unroll
-  for (int j = 0; j < E::VEC; ++j) { xa[j] = 0.f; xb[j] = 0.f; sg[j] = 0.f; sgx[j] = 0.f; }
-  constexpr int RW = MAXC * E::VEC + MAXC;
+  for (int j = 0; j < HV; ++j) { xa[j] = 0.f; xb[j] = 0.f; sg[j] = 0.f; sgx[j] = 0.f; }
+  constexpr int RW = MAXC * HV + MAXC;
   const int cx = threadIdx.x % cvb, ry = threadIdx.x / cvb;
   const int cv = blockIdx.y * cvb + cx;
-  const bool active = cv < Cp / E::VEC && ry < rows;
-  float wr[NC][E::VEC], aw[NC][E::VEC], ab[NC];
+  const bool active = cv < Cp / HV && ry < rows;
+  float wr[NC][HV], aw[NC][HV], ab[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     ab[k] = 0.f;
 #pragma unroll
-    for (int j = 0; j < E::VEC; ++j) {
-      const int c = cv * E::VEC + j;
+    for (int j = 0; j < HV; ++j) {
+      const int c = cv * HV + j;
       wr[k][j] = (active && k < ncls && c < C) ? w[(size_t)k * C + c] : 0.f;
       aw[k][j] = 0.f;
     }
   }
-  float zc[ZIN ? E::VEC : 1], zh[ZIN ? E::VEC : 1];     // ZIN: scale, shift (xa = rstd, xb = -mean * rstd)
+  float zc[ZIN ? HV : 1], zh[ZIN ? HV : 1];     // ZIN: scale, shift (xa = rstd, xb = -mean * rstd)
   if (active && (stat || ZIN)) {
 #pragma unroll
-    for (int j = 0; j < E::VEC; ++j) {
-      const int c = cv * E::VEC + j;
+    for (int j = 0; j < HV; ++j) {
+      const int c = cv * HV + j;
       const float sc = bn_scale[c], rs = bn_rstd[c];
       if constexpr (ZIN) {
         zc[j] = sc; zh[j] = bn_shift[c];
@@ -164,29 +194,29 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
   if (active) {
     // one pixel: dy, the dW / db partials and (stat) the BatchNorm reductions from the raw input vector `raw`
-    auto pixel = [&](long p, const float (&dl)[NC], const uint4 raw) {
-      float f[E::VEC], z[E::VEC], o[E::VEC];
-      unpack16<T>(raw, f);
+    auto pixel = [&](long p, const float (&dl)[NC], const Raw raw) {
+      float f[HV], z[HV], o[HV];
+      HeadVec<T>::unpack(raw, f);
       if constexpr (ZIN) {
 #pragma unroll
-        for (int j = 0; j < E::VEC; ++j) { z[j] = f[j]; f[j] = fmaxf(fmaf(f[j], zc[j], zh[j]), 0.f); }
-        unpack16<T>(pack16<T>(f), f);               // the value segk_bn_relu_apply would have stored
+        for (int j = 0; j < HV; ++j) { z[j] = f[j]; f[j] = fmaxf(fmaf(f[j], zc[j], zh[j]), 0.f); }
+        HeadVec<T>::unpack(HeadVec<T>::pack(f), f);               // the value segk_bn_relu_apply would have stored
       }
 #pragma unroll
-      for (int j = 0; j < E::VEC; ++j) o[j] = 0.f;
+      for (int j = 0; j < HV; ++j) o[j] = 0.f;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         ab[k] += dl[k];
 #pragma unroll
-        for (int j = 0; j < E::VEC; ++j) {
+        for (int j = 0; j < HV; ++j) {
           o[j] = fmaf(dl[k], wr[k][j], o[j]);
           aw[k][j] = fmaf(dl[k], f[j], aw[k][j]);
         }
       }
-      *(uint4*)(dy + (size_t)p * Cp + cv * E::VEC) = pack16<T>(o);
+      *(Raw*)(dy + (size_t)p * Cp + cv * HV) = HeadVec<T>::pack(o);
       if (stat) {
 #pragma unroll
-        for (int j = 0; j < E::VEC; ++j) {
+        for (int j = 0; j < HV; ++j) {
           const float gg = f[j] > 0.f ? o[j] : 0.f;
           sg[j] += gg;
           sgx[j] = fmaf(gg, fmaf(ZIN ? z[j] : f[j], xa[j], xb[j]), sgx[j]);
@@ -205,29 +235,37 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       r += d;
       while (r >= HW) { r -= HW; ++b; }
     };
-    // two pixels per iteration: both loads are in flight before either is used (the loop is latency-bound otherwise)
+    // PIF pixels per iteration: all their loads are in flight before the first is used (the loop is latency-bound otherwise);
+    // every pixel stream carries its own (image, offset)
+#ifndef HEAD_BWD_PIF
+#define HEAD_BWD_PIF 2
+#endif
+    constexpr int PIF = HEAD_BWD_PIF;
     const long step = (long)gridDim.x * rows;
     long p = (long)blockIdx.x * rows + ry;
-    long bA = 0, rA = 0;
-    if (p < P) split_hw(p, HW, bA, rA);
-    long bB = bA, rB = rA;
-    advance(bB, rB, step);
-    for (; p + step < P; p += 2 * step) {
-      float dl0[NC], dl1[NC];
-      const uint4 r0 = *(const uint4*)(y + (size_t)p * Cp + cv * E::VEC);
-      const uint4 r1 = *(const uint4*)(y + (size_t)(p + step) * Cp + cv * E::VEC);
-      load_dl(bA, rA, dl0);
-      load_dl(bB, rB, dl1);
-      pixel(p, dl0, r0);
-      pixel(p + step, dl1, r1);
-      advance(bA, rA, 2 * step);
-      advance(bB, rB, 2 * step);
+    long bS[PIF], rS[PIF];
+    bS[0] = 0; rS[0] = 0;
+    if (p < P) split_hw(p, HW, bS[0], rS[0]);
+#pragma unroll
+    for (int u = 1; u < PIF; ++u) { bS[u] = bS[u - 1]; rS[u] = rS[u - 1]; advance(bS[u], rS[u], step); }
+    for (; p + (PIF - 1) * step < P; p += PIF * step) {
+      float dl[PIF][NC];
+      Raw rw[PIF];
+#pragma unroll
+      for (int u = 0; u < PIF; ++u) rw[u] = *(const Raw*)(y + (size_t)(p + u * step) * Cp + cv * HV);
+#pragma unroll
+      for (int u = 0; u < PIF; ++u) load_dl(bS[u], rS[u], dl[u]);
+#pragma unroll
+      for (int u = 0; u < PIF; ++u) pixel(p + u * step, dl[u], rw[u]);
+#pragma unroll
+      for (int u = 0; u < PIF; ++u) advance(bS[u], rS[u], PIF * step);
     }
-    if (p < P) {
+    for (; p < P; p += step) {                      // tail: one pixel at a time, stream 0 walks on by one step
       float dl0[NC];
-      const uint4 r0 = *(const uint4*)(y + (size_t)p * Cp + cv * E::VEC);
-      load_dl(bA, rA, dl0);
+      const Raw r0 = *(const Raw*)(y + (size_t)p * Cp + cv * HV);
+      load_dl(bS[0], rS[0], dl0);
       pixel(p, dl0, r0);
+      advance(bS[0], rS[0], step);
     }
   }
   if (ry < rows) {
@@ -235,25 +273,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
 #pragma unroll
-      for (int j = 0; j < E::VEC; ++j) q[k * E::VEC + j] = aw[k][j];
-      q[MAXC * E::VEC + k] = ab[k];
+      for (int j = 0; j < HV; ++j) q[k * HV + j] = aw[k][j];
+      q[MAXC * HV + k] = ab[k];
     }
   }
   __syncthreads();
-  if (ry == 0 && cv < Cp / E::VEC) {
+  if (ry == 0 && cv < Cp / HV) {
     // part layout: [block][MAXC][Cp + 1]  (last column = bias gradient, written by channel vector 0)
     float* dst = part + (size_t)blockIdx.x * MAXC * (Cp + 1);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
 #pragma unroll
-      for (int j = 0; j < E::VEC; ++j) {
+      for (int j = 0; j < HV; ++j) {
         float s = 0.f;
-        for (int r2 = 0; r2 < rows; ++r2) s += red[((size_t)r2 * cvb + cx) * RW + k * E::VEC + j];   // fixed order
-        dst[k * (Cp + 1) + cv * E::VEC + j] = s;
+        for (int r2 = 0; r2 < rows; ++r2) s += red[((size_t)r2 * cvb + cx) * RW + k * HV + j];   // fixed order
+        dst[k * (Cp + 1) + cv * HV + j] = s;
       }
       if (cv == 0) {
         float s = 0.f;
-        for (int r2 = 0; r2 < rows; ++r2) s += red[((size_t)r2 * cvb + cx) * RW + MAXC * E::VEC + k];
+        for (int r2 = 0; r2 < rows; ++r2) s += red[((size_t)r2 * cvb + cx) * RW + MAXC * HV + k];
         dst[k * (Cp + 1) + Cp] = s;
       }
     }
@@ -263,19 +301,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     if (ry < rows) {
       float* q = red + ((size_t)ry * cvb + cx) * RW;
 #pragma unroll
-      for (int j = 0; j < E::VEC; ++j) { q[j] = sg[j]; q[E::VEC + j] = sgx[j]; }
+      for (int j = 0; j < HV; ++j) { q[j] = sg[j]; q[HV + j] = sgx[j]; }
     }
     __syncthreads();
-    if (ry == 0 && cv < Cp / E::VEC) {
+    if (ry == 0 && cv < Cp / HV) {
 #pragma unroll
-      for (int j = 0; j < E::VEC; ++j) {
+      for (int j = 0; j < HV; ++j) {
         float a = 0.f, b2 = 0.f;
         for (int r2 = 0; r2 < rows; ++r2) {   // fixed order
           const float* q = red + ((size_t)r2 * cvb + cx) * RW;
           a += q[j];
-          b2 += q[E::VEC + j];
+          b2 += q[HV + j];
         }
-        ((float2*)bnpart)[(size_t)blockIdx.x * Cp + cv * E::VEC + j] = make_float2(a, b2);
+        ((float2*)bnpart)[(size_t)blockIdx.x * Cp + cv * HV + j] = make_float2(a, b2);
       }
     }
   }
@@ -626,13 +664,13 @@ template <typename T>
 static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy, float* part, float* dw, float* db,
                       long P, long HW, int Cp, int C, int ncls, const float* const* bn, float* bnpart, bool zin,
                       hipStream_t st) {
-  using E = ET<T>;
-  const int cvec = Cp / E::VEC;
+  constexpr int HV = HeadVec<T>::HV;
+  const int cvec = Cp / HV;
   const int cvb = cvec < 64 ? cvec : 64;
   const int rows = 256 / cvb, gy = cdiv(cvec, cvb);
   const int nb = segk_head_blocks(P);
-  const size_t lds = (size_t)rows * cvb * (MAXC * E::VEC + MAXC) * sizeof(float);
-  SEGK_REQUIRE(gy == 1, "head_bwd: at most %d input channels supported", 64 * E::VEC);
+  const size_t lds = (size_t)rows * cvb * (MAXC * HV + MAXC) * sizeof(float);
+  SEGK_REQUIRE(gy == 1, "head_bwd: at most %d input channels supported", 64 * HV);
   auto launch_z = [&](auto NCc, auto ZINc) {
     constexpr int NC = decltype(NCc)::value;
     auto kern = head_bwd_kernel<T, NC, decltype(ZINc)::value>;
