@@ -466,6 +466,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #define PIPE_STAMP(i) do {} while (0)
 #define PIPE_STAMP_OUT() do {} while (0)
 #endif
+#ifndef PIPE_ILV
+#define PIPE_ILV 1     // 16x16x32 consumers read the next sub-step's fragments between the MFMAs (0: in a group ahead of them, rounds 2-3)
+#endif
 #ifndef PIPE_ABL
 #define PIPE_ABL 0     // diagnostic ablations (results are wrong): 1 producers skip LDS stores, 2 skip global loads, 4 consumers re-use fragments
 #endif
@@ -917,6 +920,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int t = i >> 1, hh = i & 1;
+#if PIPE_ILV
+      // Round 4: the next sub-step's fragments are read BETWEEN this sub-step's MFMAs, one ds_read_b128 behind every
+      // second MFMA (weight fragments of a new tap first: the next sub-step's first MFMAs need all four).  A consumer is
+      // alone on its SIMD's matrix pipe: while it issues a group of 4-8 reads back to back the pipe runs dry (tools/ubench/
+      // pipe_roles.hip: 1968 -> 1652 cycles per 1536-cycle step in the bare loop, 2006 -> 1806 beside staging partners).
+      {
+        const int ni = (i + 1) % 6, nt_ = ni >> 1, nh = ni & 1;
+        const int rp = (i + 1 < 6) ? prow : prow_next;
+        const int rw = (i + 1 < 6) ? wb : wb_next;
+        const bool needB = (nh == 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc[4 * hh + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i & 1][j]),
+                                                                          __builtin_bit_cast(bf16x8, fb[t][nb]), acc[4 * hh + j][nb],
+                                                                          0, 0, 0);
+            const int m = j * NB + nb;
+            if ((m & 1) && !(PIPE_ABL & 4)) {
+              const int r = m >> 1;   // 0 .. 7
+              if (needB) {
+                if (r < 4) fb[nt_][r] = *(const uint4*)(smem + rw + laneB[r] + nt_ * (BN * WPIX));
+                else fa[(i + 1) & 1][r - 4] = *(const uint4*)(smem + rp + laneA[4 * nh + r - 4] + nt_ * PPIX);
+              } else if (r < 4) {
+                fa[(i + 1) & 1][r] = *(const uint4*)(smem + rp + laneA[4 * nh + r] + nt_ * PPIX);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        continue;
+      }
+#endif
       if (i + 1 < 6) {
         rdA(prow, (i + 1) >> 1, (i + 1) & 1, fa[(i + 1) & 1]);
         if (((i + 1) & 1) == 0) rdB(wb, (i + 1) >> 1, fb[(i + 1) >> 1]);
