@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsegk.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 300          # SEGK_ABI_VERSION of the include/segk.h this table was written against
+ABI_VERSION = 310          # SEGK_ABI_VERSION of the include/segk.h this table was written against
 MAX_CLASSES = 8
 
 _vp, _fp, _i, _l, _f, _d = C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
@@ -20,6 +20,7 @@ SIGNATURES = {
     "segk_version": (_i, []),
     "segk_entry_count": (_i, []),
     "segk_clock_probe": (_i, [_vp, _i, _i, _i, _vp]),
+    "segk_debug_poison_tickets": (_i, [C.c_uint64, _vp]),
     "segk_build_id": (C.c_char_p, []),
     "segk_last_error": (C.c_char_p, []),
     "segk_nchw_to_nhwc": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

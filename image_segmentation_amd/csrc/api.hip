@@ -41,6 +41,7 @@ int segk_prompt_mix_impl(const float*, const float*, const float*, float*, int, 
 int segk_confusion_impl(const float*, const long long*, int, int, long, unsigned long long*, hipStream_t);
 
 int segk_clock_probe_impl(unsigned long long*, int, int, int, hipStream_t);
+int segk_debug_poison_tickets_impl(unsigned long long, hipStream_t);
 
 int segk_device_index() {
   int dev = 0;
@@ -68,6 +69,9 @@ extern "C" {
 #endif
 int segk_version(void) { return SEGK_ABI_VERSION; }
 int segk_entry_count(void) { return SEGK_ENTRY_COUNT; }
+int segk_debug_poison_tickets(uint64_t pattern, segk_stream_t s) {
+  return segk_debug_poison_tickets_impl((unsigned long long)pattern, (hipStream_t)s);
+}
 int segk_clock_probe(uint64_t* out, int blocks, int iters, int shape, segk_stream_t s) {
   return segk_clock_probe_impl((unsigned long long*)out, blocks, iters, shape, (hipStream_t)s);
 }

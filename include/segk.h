@@ -32,8 +32,8 @@ typedef void* segk_stream_t; /* hipStream_t */
 
 /* ABI version and the number of entry points this header declares: segk_version() / segk_entry_count() of a library
  * must equal them (image_segmentation_amd/_lib.py refuses a library whose values differ from the table it binds) */
-#define SEGK_ABI_VERSION 300
-#define SEGK_ENTRY_COUNT 68
+#define SEGK_ABI_VERSION 310
+#define SEGK_ENTRY_COUNT 69
 int segk_version(void);
 int segk_entry_count(void);
 /* first 16 hex digits of the sha256 over the sources this library was built from (image_segmentation_amd/build.py:
@@ -315,6 +315,12 @@ int segk_prob_loss_bwd(const float* probs, const int64_t* labels, const float* c
  * elapsed ticks of the constant 100 MHz counter (s_memrealtime): clock = out[2w] / out[2w+1] x 100 MHz.  bench.py puts
  * the median into its line so that box-to-box spread is explained by a number. */
 int segk_clock_probe(uint64_t* out, int blocks, int iters, int shape, segk_stream_t s);
+/* Overwrites every word of the device's ticket ring with `pattern` and waits for the copy.  The ring holds the arrival
+ * counters of the kernels that finish a reduction in the launch that produced its partials (segk_bn_finalize above 1024
+ * partial rows, segk_loss_fwd / segk_prob_loss_fwd); a word is {generation : 32 | arrivals : 32} and a launch starts its
+ * count over when it finds another generation, so ANY content is a valid starting state.  Tests use this entry to leave
+ * behind what an aborted launch or a stray store would (tests/test_gpu_kernels.py); generation 0xffffffff is never issued. */
+int segk_debug_poison_tickets(uint64_t pattern, segk_stream_t s);
 
 /* ---- metric: argmax + confusion matrix (utils/MetricsHistory.py:65-75) ---------------------------
  * M[pred*8 + label] += count (uint64, caller zeroes); TP/FP/FN/TN follow on the host. */

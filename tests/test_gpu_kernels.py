@@ -351,6 +351,43 @@ def test_maxpool(ops, dtype, shape):
     assert torch.equal(back(xa.grad), x.grad)
 
 
+@pytest.mark.parametrize("pattern", [0xffffffff00000005, 0xffffffffffffffff, 0x0000000000000003, 0x0000002a00000001],
+                         ids=["stale_generation_count5", "all_ones", "generation0_count3", "generation42_count1"])
+def test_ticket_ring_survives_poisoned_slots(ops, pattern):
+    """The in-launch finishers (segk_bn_finalize above 1024 partial rows, segk_loss_fwd) elect the last-arriving block through a
+    ticket word of a process-wide ring (csrc/ticket.hpp).  Rounds 2-3 relied on every word being zero when a launch drew
+    it -- a launch that aborted left its counters behind and a later launch on that slot never elected a finisher
+    (scale / shift stayed uninitialised, silently).  The words are now {generation | arrivals}: whatever they hold, a launch
+    starts its own count.  Here EVERY word of the ring is overwritten (segk_debug_poison_tickets) with what an aborted launch
+    or a stray store would leave, and both kernels must still produce the reference values, repeatedly."""
+    from image_segmentation_amd import _lib, losses
+    MT, C = 3000, 128
+    g = torch.Generator().manual_seed(77)
+    rows = torch.rand((MT, C, 2), generator=g, dtype=torch.float32)
+    rows[:, :, 1] = rows[:, :, 1] * 4 + 3.0
+    count = float(MT * 4)
+    gamma, beta = fill((C,), 1, 0.5, 1.5), fill((C,), 2, -0.5, 0.5)
+    st = torch.empty((_lib.query("segk_bn_stats_floats", MT, C),), dtype=torch.float32, device="cuda")
+    s = rows.double().sum(0)
+    mean = s[:, 0] / count
+    rstd = 1.0 / torch.sqrt((s[:, 1] / count - mean * mean).clamp(min=0) + 1e-5)
+    lg0 = fill((4, 3, 64, 96), 41, -3, 3); Y = fill_labels((4, 64, 96), 42, 3)
+    want_loss = torch.nn.functional.cross_entropy(lg0, Y).item()
+    stream = torch.cuda.current_stream().cuda_stream
+    for rep in range(3):
+        _lib.call("segk_debug_poison_tickets", pattern + rep * (pattern != 0xffffffffffffffff), stream)   # count 5, 6, 7 ...
+        st[:MT * C * 2] = dev(rows).reshape(-1)
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        sc, sh, mu, rs = ops.bn_finalize(st, MT, C, count, None, dev(gamma), dev(beta), rm, rv, 0.1, 1e-5, True, "cuda")
+        torch.cuda.synchronize()
+        assert (back(mu).double() - mean).abs().max() < 1e-6
+        assert (back(sc).double() - gamma.double() * rstd).abs().max() < 1e-5
+        assert (back(sh).double() - (beta.double() - mean * gamma.double() * rstd)).abs().max() < 1e-5
+        for _ in range(3):                                       # several draws: slots straight after the poisoning and later ones
+            v = losses.CrossEntropyLoss()(dev(lg0), dev(Y))
+            assert abs(v.item() - want_loss) < 5e-6
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_loss_kernels(ops, dtype, golden):
     if dtype != torch.float32:
