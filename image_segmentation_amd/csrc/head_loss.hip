@@ -670,7 +670,8 @@ static int head_bwd_t(const float* dlog, const void* y, const float* w, void* dy
   const int rows = 256 / cvb, gy = cdiv(cvec, cvb);
   const int nb = segk_head_blocks(P);
   const size_t lds = (size_t)rows * cvb * (MAXC * HV + MAXC) * sizeof(float);
-  SEGK_REQUIRE(gy == 1, "head_bwd: at most %d input channels supported", 64 * HV);
+  // gy > 1 (more than 64 channel vectors: above 256 channels): blockIdx.y slices the channels; every slice walks the
+  // block's pixels and writes its own columns of the partial rows (tests/test_gpu_kernels.py at 288 and 512 channels)
   auto launch_z = [&](auto NCc, auto ZINc) {
     constexpr int NC = decltype(NCc)::value;
     auto kern = head_bwd_kernel<T, NC, decltype(ZINc)::value>;

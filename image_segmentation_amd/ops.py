@@ -9,6 +9,7 @@ dtype (fp32 = parity mode, bf16 = performance mode).  For C % 32 == 0 this is ex
 channels_last memory format.
 """
 import os
+import sys
 import weakref
 
 import torch
@@ -1005,6 +1006,7 @@ class DoubleConvFn(torch.autograd.Function):
             pdy, keep = dy_buf.data_ptr(), dy_buf
         elif cfg.emit_pool:
             dy, dpool = grads
+            rc_skip, rc_pool = sys.getrefcount(dy), sys.getrefcount(dpool)   # before anything below takes references
             if dpool is None:
                 keep, pdy, _ = _raw(dy, dtype)
             else:
@@ -1018,8 +1020,15 @@ class DoubleConvFn(torch.autograd.Function):
                     # a pooling backward plus a full-resolution add.  A backward must not change a gradient somebody
                     # else can still see: with a tensor hook on the skip tensor (register_hook: the hook may keep the
                     # tensor it is handed; retain_grad() clones and is safe) the sum goes to a private copy instead.
+                    # Autograd itself can hold it too: torch.autograd.grad(loss, [skip]) CAPTURES the very tensor this
+                    # backward is handed (no clone).  Every other holder shows in the tensor's reference counts -- the
+                    # engine's input buffer and this frame account for a TensorImpl use count of 2, a capture makes it 3;
+                    # a hook that outlived the Python skip tensor and stashed its argument raises the Python reference
+                    # count above that of the sibling gradient that arrived in the same tuple.
                     yo = getattr(ctx, "y_ref", lambda: None)()
-                    hooked = INPLACE_SKIP_GRAD is False or (yo is not None and bool(yo._backward_hooks))
+                    uc = getattr(dy, "_use_count", None)
+                    shared = uc is None or uc() > 2 or rc_skip > rc_pool
+                    hooked = INPLACE_SKIP_GRAD is False or shared or (yo is not None and bool(yo._backward_hooks))
                     keep, pdy, _ = _raw(dy, dtype)
                     if hooked and keep.data_ptr() == dy.data_ptr():      # zero-copy act tensor: the caller's own storage
                         keep = _private_act_copy(keep, dtype)

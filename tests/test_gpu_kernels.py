@@ -351,6 +351,36 @@ def test_maxpool(ops, dtype, shape):
     assert torch.equal(back(xa.grad), x.grad)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [64, 280, 512])
+def test_output_head_any_width(ops, dtype, C):
+    """Output Conv2d(C, classes, 1) forward + backward (reference unet/unet.py:91, clip/clipunet.py:181: nn.Conv2d accepts any
+    width; UNetDecoder(decoder_channels=[..., C]) feeds it C channels).  The backward kernel owns 4 channels per thread
+    and 64 channel vectors per block row: above 256 padded channels it runs channel slices (blockIdx.y) -- refused with -2
+    until round 4."""
+    import types
+    B, H, W, ncls = 2, 24, 40, 3
+    x = fill((B, C, H, W), 5, -1, 1); w = fill((ncls, C, 1, 1), 6, -0.2, 0.2); b = fill((ncls,), 7, -0.1, 0.1)
+    gl = fill((B, ncls, H, W), 8, -1, 1)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    if dtype == torch.bfloat16:
+        xq = xr.to(dtype).float()
+    else:
+        xq = xr
+    ref = torch.nn.functional.conv2d(xq, wr, br)
+    ref.backward(gl)
+    xd = dev(x).to(memory_format=torch.channels_last).requires_grad_(True)
+    wd = dev(w).requires_grad_(True); bd = dev(b).requires_grad_(True)
+    lg = ops.HeadFn.apply(types.SimpleNamespace(compute_dtype=dtype), xd, wd, bd)
+    lg.backward(dev(gl))
+    torch.cuda.synchronize()
+    t = 2e-5 if dtype == torch.float32 else 3e-2
+    assert (back(lg) - ref.detach()).abs().max().item() < t * (C ** 0.5) * 0.2
+    assert (back(xd.grad).float() - xr.grad).abs().max().item() < (1e-5 if dtype == torch.float32 else 8e-3)
+    assert (back(wd.grad) - wr.grad).abs().max().item() < t * (B * H * W) ** 0.5 * 0.2
+    assert (back(bd.grad) - br.grad).abs().max().item() < 1e-3
+
+
 @pytest.mark.parametrize("pattern", [0xffffffff00000005, 0xffffffffffffffff, 0x0000000000000003, 0x0000002a00000001],
                          ids=["stale_generation_count5", "all_ones", "generation0_count3", "generation42_count1"])
 def test_ticket_ring_survives_poisoned_slots(ops, pattern):

@@ -499,4 +499,27 @@ def test_skip_gradient_seen_by_a_tensor_hook_is_not_modified_in_place(seg, dtype
     (out.float() * fill(tuple(out.shape), 7, -1, 1).cuda()).sum().backward()
     torch.cuda.synchronize()
     assert torch.equal(skip_grad, yd.grad.float())
+    # the same gradient captured by autograd itself (no hook anywhere: torch.autograd.grad hands out the very tensor the
+    # pooling backward receives) and by a hook that outlives the Python skip tensor
+    for how in ("autograd.grad", "orphan hook"):
+        dc = seg.DoubleConvReLU(3, 64); down = seg.Down(64, 128); up = seg.Up(128, 64)
+        fill_module(dc, 1000); fill_module(down, 2000); fill_module(up, 3000)
+        dc.cuda().train(); down.cuda().train(); up.cuda().train()
+        y, pooled = dc(x, emit_pool=True)
+        out = up(y, down(y, pooled=pooled))
+        loss = (out.float() * fill(tuple(out.shape), 7, -1, 1).cuda()).sum()
+        if how == "autograd.grad":
+            del pooled
+            got, gw = torch.autograd.grad(loss, [y, dc.doubleConvReLU[0].weight])
+        else:
+            seen = []
+            y.register_hook(lambda g: seen.append(g))
+            del y, pooled, out
+            loss.backward()
+            got, gw = seen[0], dc.doubleConvReLU[0].weight.grad
+        torch.cuda.synchronize()
+        # the captured tensor is the gradient of the skip connection alone (the pooled path reaches the block through its
+        # second output), unchanged by the backward that consumed it; the parameter gradients are those of the plain run
+        assert torch.equal(gw.float(), g0["doubleConvReLU.0.weight"]), how
+        assert torch.equal(got.detach().float(), skip_grad), how
     seg.set_compute_dtype(torch.bfloat16)
