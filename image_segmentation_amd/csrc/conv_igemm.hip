@@ -473,11 +473,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #define PIPE_ABL 0     // diagnostic ablations (results are wrong): 1 producers skip LDS stores, 2 skip global loads, 4 consumers re-use fragments
 #endif
 
-template <int TWL, bool PRO, int BN, bool M16>
+// DMA (round 4; 16x16x32 consumers, no prologue): the producers move NOTHING through registers.  Weights and patch arrive by
+// LDS-DMA (global_load_lds, 1 KiB per wave-instruction, out-of-image halo pixels from a zero page), so a staged KiB costs the
+// SIMD one issue instead of a global load plus a ds_write_b128 (tools/ubench/pipe_roles.hip: +38 instead of +154 cycles per
+// 1536-cycle step beside the consumer), and the consumers' matrix stream is the only LDS writer-free critical path.  A DMA
+// instruction writes 64 consecutive 16-byte slots, so both images are unpadded and conflict freedom comes from WHICH piece a
+// lane fetches: weight rows keep the XOR image above (it never had padding); the patch becomes rows of 8-pixel blocks of
+// 512 B with piece q of pixel x at (x >> 3) * 512 + (q >> 1) * 256 + ((6 x + q) & 15) * 16 -- the slot map of conv_rs.hip,
+// conflict-free for a 16-pixel operand read at ANY x shift; a 16-pixel block starts at x = 0 or 16, so the consumers need
+// one per-lane address per tap column (three registers instead of eight) plus immediates.  The epilogue tile overlays only
+// [P1 | W2 | spare]: the next unit's first patch chunk (P0) and weight steps (W0, W1) land while this unit finishes, and the
+// third boundary barrier is gone.
+__device__ __attribute__((aligned(256))) unsigned char g_pipe_zero_page[256];
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+template <int TWL, bool PRO, int BN, bool M16, bool DMA = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) {
   using T = bf16_t;
   using E = ET<T>;
-  constexpr int PPIX = M16 ? 96 : PIXB;            // LDS pitch of a patch pixel's chunk
+  static_assert(!DMA || (M16 && !PRO), "the LDS-DMA form serves the 16x16x32 consumers without a prologue");
+  constexpr int PPIX = DMA ? 64 : (M16 ? 96 : PIXB);   // LDS pitch of a patch pixel's chunk
   constexpr int WPIX = M16 ? 64 : PIXB;            // LDS pitch of a weight row
   // workgroup tile 256 px x 128 ch (consumers 2 x 2) or, for 64-channel layers, 512 px x 64 ch (consumers 4 x 1):
   // the same bytes per step and the same 128 x 64 consumer tile either way
@@ -485,7 +501,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   constexpr int BM = 32768 / BN, NTHR = 512, NPT = 256;       // NPT: producer threads
   constexpr int WN = BN / 64, WM = 4 / WN, MF = 4, NF = 2;    // consumer waves: WM x WN, 128 px x 64 ch each
   constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
-  constexpr int ROWP = (PW * PPIX + 255) & ~255;
+  constexpr int RPX = (PW + 7) & ~7;               // DMA image: pixel slots per patch row (whole 8-pixel blocks)
+  constexpr int ROWP = DMA ? RPX * 64 : ((PW * PPIX + 255) & ~255);
   constexpr int PB = PH * ROWP;                    // one patch chunk
   constexpr int WB = 3 * BN * WPIX;                // one step of weights: 3 taps x 128 rows
   constexpr int NP = PH * PW * 4, NPL = (NP + NPT - 1) / NPT;
@@ -532,8 +549,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   // ---- the part of the epilogue all 512 threads run: BN-statistics reduction over the consumer rows and
   // the 16-byte coalesced NHWC stores of the staged tile
   constexpr int OP = BN * E::ES + 16;
-  static_assert(BM * OP + WM * BN * 8 <= MAINB - POFF, "epilogue tile fits behind the two live ring slots");
-  char* const ot = smem + POFF;
+  constexpr int OTOFF = DMA ? POFF + PB : POFF;    // DMA: P0 stays live across the unit boundary (next unit's first chunk)
+  constexpr int LDSEND = DMA ? (MAINB > OTOFF + BM * OP + WM * BN * 8 ? MAINB : OTOFF + BM * OP + WM * BN * 8) : MAINB;
+  static_assert(DMA ? (LDSEND + 1024 <= 160 * 1024) : (BM * OP + WM * BN * 8 <= MAINB - POFF),
+                "epilogue tile fits behind the live ring slots");
+  char* const ot = smem + OTOFF;
   float* const red = (float*)(ot + BM * OP);
   auto store_tile = [&](auto FULLc) {
     constexpr bool FULL = decltype(FULLc)::value;
@@ -568,6 +588,126 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     }
   };
 
+  if constexpr (DMA) {
+  if (wave >= 4) {
+    // =========================================== PRODUCERS (LDS-DMA) ===========================================
+    const int pw = wave - 4;                          // producer wave: pieces pw, pw + 4, ...
+    constexpr int NPIECE = PH * RPX / 16;             // patch pieces (16 pixel slots = 1 KiB) per chunk
+    static_assert(PH * RPX % 16 == 0, "whole pieces");
+    constexpr int NPL = (NPIECE + 3) / 4;             // per wave (a wave without a last piece issues it into the trash KiB)
+    constexpr int NPL0 = (NPL + 1) / 2;               // issued in the chunk's first step; the rest in its second
+    constexpr int G16 = BN / 16;                      // 16-row weight groups per tap
+    constexpr int NWL = 3 * G16 / 4;                  // weight pieces per wave and step (6 or 3)
+    static_assert(3 * G16 % 4 == 0, "weight pieces divide evenly");
+    // lane -> (pixel of the 16-slot piece, 16-byte piece q) by inverting the slot map; -> weight row / piece of a 16-row group
+    const int lb = lane >> 5, lh = (lane >> 4) & 1, ls = lane & 15;
+    const int p8 = (3 * ((ls >> 1) - lh)) & 7, pq = 2 * lh + (ls & 1);
+    const unsigned wl_off = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((0x1230 >> (4 * ((lane >> 4) & 3))) & 3)) << 4));
+    const char* const zp = (const char*)g_pipe_zero_page + ls * 16;
+    int prel[NPL];                                    // (patch row << 8) | patch column of the lane's pixel; row 32767: never valid
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int j = pw + 4 * i;
+      const int b8 = 2 * j + lb;
+      const int py = b8 / (RPX / 8), px = (b8 - py * (RPX / 8)) * 8 + p8;
+      prel[i] = (j < NPIECE && px < PW) ? ((py << 8) | px) : (0x7fff << 8);
+    }
+    unsigned pvalid = 0;
+    int plin[NPL];
+    auto patch_unit = [&](int b, int y0, int x0) {
+      pvalid = 0;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int gy = y0 + (prel[i] >> 8) - 1, gx = x0 + (prel[i] & 255) - 1;
+        const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+        plin[i] = ok ? (b * H + gy) * W + gx : 0;
+        pvalid |= (ok ? 1u : 0u) << i;
+      }
+    };
+    // pieces [I0, I1) of chunk kc into patch buffer `buf`
+    auto issue_p = [&](int kc, int buf, auto I0c, auto I1c) {
+      constexpr int I0 = decltype(I0c)::value, I1 = decltype(I1c)::value;
+      const T* base;
+      int C;
+      if (kc < nchA) { base = (const T*)a.srcA + kc * E::CH; C = a.CA; }
+      else { base = (const T*)a.srcB + (kc - nchA) * E::CH; C = a.CB; }
+      const char* const cb = (const char*)(base + pq * E::VEC);
+      const unsigned cbytes = (unsigned)C * 2u;
+#pragma unroll
+      for (int i = I0; i < I1; ++i) {
+        const int j = pw + 4 * i;                       // wave-uniform
+        char* const dst = smem + ((j < NPIECE) ? POFF + buf * PB + j * 1024 : LDSEND);
+        const char* const src = ((pvalid >> i) & 1) ? cb + (size_t)((unsigned)plin[i] * cbytes) : zp;
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)dst, 16, 0, 0);
+      }
+    };
+    // weight step `step` of the unit whose channel tile starts at n0 -> ring slot
+    auto issue_w = [&](int n0, int step, int ring) {
+      const char* const wb = (const char*)a.w + ((size_t)(step * 3) * a.Ntot + n0) * 64 + wl_off;
+      char* const dst = smem + wring(ring);
+#pragma unroll
+      for (int i = 0; i < NWL; ++i) {
+        const int j = pw + 4 * i, t = j / G16, g = j - t * G16;
+        __builtin_amdgcn_global_load_lds((glb_vp)(wb + ((size_t)t * a.Ntot * 64 + g * 1024)), (lds_vp)(dst + j * 1024), 16, 0, 0);
+      }
+    };
+    using I_0 = std::integral_constant<int, 0>;
+    using I_H = std::integral_constant<int, NPL0>;
+    using I_N = std::integral_constant<int, NPL>;
+
+    issue_w(un0, 0, 0);
+    issue_w(un0, 1, 1);
+    patch_unit(ub, uy0, ux0);
+    issue_p(0, 0, I_0{}, I_N{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // B0
+    for (;;) {
+      const int un = u + GW;
+      const bool has_next = un < u_end;
+      int nmt = 0, nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
+      if (has_next) decode(un, nmt, nb, ny0, nx0, nn0);
+      for (int kc = 0; kc < nchunks; ++kc) {
+        const int s0 = 3 * kc;
+        const bool last = (kc + 1 == nchunks);
+        // ---- step TG0: weights of step s0 + 2 (slot 2); first half of the next chunk's patch (the next unit's chunk 0 into
+        // P0 behind the last chunk: nchunks is even, so the last chunk lives in P1)
+        issue_w(un0, s0 + 2, 2);
+        if (!last) {
+          issue_p(kc + 1, (kc + 1) & 1, I_0{}, I_H{});
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL0) : "memory");     // the weights (older) have landed
+        } else if (has_next) {
+          patch_unit(nb, ny0, nx0);
+          issue_p(0, 0, I_0{}, I_H{});
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL0) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // raw s_barrier: __syncthreads() carries a fence that hipcc lowers to s_waitcnt vmcnt(0) -- it would drain the patch
+        // pieces this step leaves in flight.  The DMA data a barrier publishes is covered by the counted wait above it.
+        __builtin_amdgcn_s_barrier();
+        // ---- step TG1: weights of step s0 + 3 (slot 0: the next chunk's or the next unit's first step); rest of the patch
+        if (!last) issue_w(un0, s0 + 3, 0);
+        else if (has_next) issue_w(nn0, 0, 0);
+        if (!last) issue_p(kc + 1, (kc + 1) & 1, I_H{}, I_N{});
+        else if (has_next) issue_p(0, 0, I_H{}, I_N{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- step TG2: weights of step s0 + 4 (slot 1)
+        if (!last) issue_w(un0, s0 + 4, 1);
+        else if (has_next) issue_w(nn0, 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      __syncthreads();                                 // E1: the consumers have staged the output tile
+      if ((uy0 + TH <= H) && (ux0 + TW <= W)) store_tile(std::true_type{});
+      else store_tile(std::false_type{});
+      if (!has_next) break;
+      __syncthreads();                                 // E2: tile consumed, [P1 | W2 | spare] may be rewritten
+      u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
+    }
+    return;
+  }
+  } else {
   if (wave >= 4) {
     // =========================================== PRODUCERS ===========================================
     // wave priorities stay at their default: raising the producers (s_setprio 3) or the consumers (2) was measured
@@ -744,6 +884,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     PIPE_STAMP_OUT();
     return;
   }
+  }
 
   // ============================================= CONSUMERS =============================================
   if constexpr (!M16) {
@@ -876,12 +1017,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   const int wm = wave / WN, wn = wave - wm * WN;
   const int lc = lane & 15, lq = lane >> 4;
   constexpr int MB = 8, NB = 4;
-  int laneA[MB], laneB[NB];
+  int laneA[DMA ? 3 : MB], laneB[NB];
+  if constexpr (DMA) {
+    // one address per tap column t: pixel x = (block start: 0 or 16) + t + lc of the wave's first tile row; pixel block mb
+    // adds the immediate mboff(mb)
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int m = (wm * MB + mb) * 16 + lc;
-    laneA[mb] = POFF + (m >> TWL) * ROWP + (m & (TW - 1)) * PPIX + lq * 16;
+    for (int t = 0; t < 3; ++t)
+      laneA[t] = POFF + ((wm * MB * 16) >> TWL) * ROWP + ((t + lc) >> 3) * 512 + (lq >> 1) * 256 + ((6 * (t + lc) + lq) & 15) * 16;
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = (wm * MB + mb) * 16 + lc;
+      laneA[mb] = POFF + (m >> TWL) * ROWP + (m & (TW - 1)) * PPIX + lq * 16;
+    }
   }
+  // byte address of the lane's 16 bytes of pixel block mb at tap column t, relative to the patch row base `prow`
+  auto pa = [&](int prow, int mb, int t) -> const char* {
+    if constexpr (DMA) return smem + prow + laneA[t] + (((mb * 16) >> TWL) * ROWP + (((mb * 16) & (TW - 1)) >> 3) * 512);
+    else return smem + prow + laneA[mb] + t * PPIX;
+  };
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
     laneB[nb] = ((wn * NB + nb) * 16 + lc) * WPIX + ((lq ^ ((0x1230 >> (4 * ((lc >> 2) & 3))) & 3)) << 4);
@@ -901,7 +1055,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       return;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) A[j] = *(const uint4*)(smem + prow + laneA[4 * hh + j] + t * PPIX);
+    for (int j = 0; j < 4; ++j) A[j] = *(const uint4*)pa(prow, 4 * hh + j, t);
   };
   auto rdB = [&](int wb, int t, uint4 (&Bf)[NB]) {
     if (PIPE_ABL & 4) {
@@ -942,9 +1096,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
               const int r = m >> 1;   // 0 .. 7
               if (needB) {
                 if (r < 4) fb[nt_][r] = *(const uint4*)(smem + rw + laneB[r] + nt_ * (BN * WPIX));
-                else fa[(i + 1) & 1][r - 4] = *(const uint4*)(smem + rp + laneA[4 * nh + r - 4] + nt_ * PPIX);
+                else fa[(i + 1) & 1][r - 4] = *(const uint4*)pa(rp, 4 * nh + r - 4, nt_);
               } else if (r < 4) {
-                fa[(i + 1) & 1][r] = *(const uint4*)(smem + rp + laneA[4 * nh + r] + nt_ * PPIX);
+                fa[(i + 1) & 1][r] = *(const uint4*)pa(rp, 4 * nh + r, nt_);
               }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1050,7 +1204,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     zero_acc();
     __syncthreads();                                   // E2
     u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
-    __syncthreads();                                   // E3: the next unit's chunk 0 is in P0
+    if constexpr (!DMA) __syncthreads();               // E3: the next unit's chunk 0 is in P0 (DMA: it landed before E1)
     PIPE_STAMP(4);
     rdA(0, 0, 0, fa[0]);
     rdB(0, 0, fb[0]);
@@ -1339,13 +1493,16 @@ int launch_ws(ConvArgs a, hipStream_t st) {
   return 0;
 }
 
-template <int TWL, bool PRO, int BN, bool M16>
+template <int TWL, bool PRO, int BN, bool M16, bool DMA = false>
 int launch_pipe_m(ConvArgs a, hipStream_t st) {
   constexpr int BM = 32768 / BN, NTHR = 512;
   constexpr int TW = 1 << TWL, TH = BM >> TWL, PW = TW + 2, PH = TH + 2;
-  constexpr int PPIX = M16 ? 96 : PIXB, WPIX = M16 ? 64 : PIXB;
-  constexpr int ROWP = (PW * PPIX + 255) & ~255;
-  constexpr size_t lds = 3 * (size_t)(3 * BN * WPIX) + 2 * (size_t)PH * ROWP + (NTHR / 2) * 16;   // + producers' trash slots
+  constexpr int PPIX = DMA ? 64 : (M16 ? 96 : PIXB), WPIX = M16 ? 64 : PIXB;
+  constexpr int ROWP = DMA ? ((PW + 7) & ~7) * 64 : ((PW * PPIX + 255) & ~255);
+  constexpr size_t ring = 3 * (size_t)(3 * BN * WPIX) + 2 * (size_t)PH * ROWP;
+  // DMA: the epilogue tile (+ statistics rows) starts behind [W0 | W1 | P0]; one trash KiB at the end
+  constexpr size_t epi = 2 * (size_t)(3 * BN * WPIX) + (size_t)PH * ROWP + (size_t)BM * (BN * 2 + 16) + (size_t)(4 / (BN / 64)) * BN * 8;
+  constexpr size_t lds = DMA ? (ring > epi ? ring : epi) + 1024 : ring + (NTHR / 2) * 16;   // + producers' trash slots
   static_assert(lds <= 160 * 1024, "conv3x3_pipe: LDS exceeds 160 KiB");
   a.twl = TWL;
   a.tiles_x = cdiv(a.W, TW);
@@ -1355,7 +1512,7 @@ int launch_pipe_m(ConvArgs a, hipStream_t st) {
   int gw = num_cus() / 8;                                  // one 8-wave workgroup per CU
   if (gw > per_xcd) gw = per_xcd;
   a.persistent = 1;
-  auto kern = conv3x3_pipe_kernel<TWL, PRO, BN, M16>;
+  auto kern = conv3x3_pipe_kernel<TWL, PRO, BN, M16, DMA>;
   static bool attr_set[SEGK_MAX_DEVICES] = {};
   const int dev = segk_device_index();
   if (!attr_set[dev]) {
@@ -1377,6 +1534,16 @@ int launch_pipe(ConvArgs a, hipStream_t st) {
   // for the A/B switch.
   static const char* const force = getenv("SEGK_PIPE_MFMA");  // A/B switch for tools/kbench.py / tools/ab_bench.sh: "16" or "32"
   const bool m16 = force ? (force[0] == '1') : true;
+  if constexpr (!PRO) {
+    // LDS-DMA producers (round 4): layers without a BatchNorm prologue whose chunk count is even (the patch ring's parity
+    // across the unit boundary) and whose sources stay below 4 GiB (32-bit byte offsets per DMA lane)
+    static const char* const nodma = getenv("SEGK_PIPE_DMA");  // "0": the register-staged producers of rounds 1-3 (A/B runs)
+    const int nchunks = (a.CA + a.CB) / 32;
+    const long long px = (long long)a.B * a.H * a.W;
+    const int cmax = a.CA > a.CB ? a.CA : a.CB;
+    if (m16 && !(nodma && nodma[0] == '0') && nchunks % 2 == 0 && px * cmax * 2 < 4294967296LL)
+      return launch_pipe_m<TWL, PRO, BN, true, true>(a, st);
+  }
   return m16 ? launch_pipe_m<TWL, PRO, BN, true>(a, st) : launch_pipe_m<TWL, PRO, BN, false>(a, st);
 }
 
