@@ -469,8 +469,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #ifndef PIPE_ILV
 #define PIPE_ILV 1     // 16x16x32 consumers read the next sub-step's fragments between the MFMAs (0: in a group ahead of them, rounds 2-3)
 #endif
+#ifndef PIPE_RAWBAR
+#define PIPE_RAWBAR 0  // 1: the 16x16x32 consumers' step barriers as a raw s_barrier (no lgkmcnt(0) drain): 12.31 vs 12.29-12.30 ms, no gain
+#endif
+__device__ __forceinline__ void step_barrier() {
+#if PIPE_RAWBAR
+  __builtin_amdgcn_s_barrier();
+#else
+  __syncthreads();
+#endif
+}
 #ifndef PIPE_ABL
-#define PIPE_ABL 0     // diagnostic ablations (results are wrong): 1 producers skip LDS stores, 2 skip global loads, 4 consumers re-use fragments
+#define PIPE_ABL 0     // diagnostic ablations (results are wrong): 1 producers skip LDS stores, 2 skip global loads, 4 consumers re-use fragments,
+                       // 8 DMA form: no output stores, 16 DMA form: no statistics reduction, 32 DMA form: no epilogue at all
 #endif
 
 // DMA (round 4; 16x16x32 consumers, no prologue): the producers move NOTHING through registers.  Weights and patch arrive by
@@ -481,12 +492,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 // lane fetches: weight rows keep the XOR image above (it never had padding); the patch becomes rows of 8-pixel blocks of
 // 512 B with piece q of pixel x at (x >> 3) * 512 + (q >> 1) * 256 + ((6 x + q) & 15) * 16 -- the slot map of conv_rs.hip,
 // conflict-free for a 16-pixel operand read at ANY x shift; a 16-pixel block starts at x = 0 or 16, so the consumers need
-// one per-lane address per tap column (three registers instead of eight) plus immediates.  The epilogue tile overlays only
-// [P1 | W2 | spare]: the next unit's first patch chunk (P0) and weight steps (W0, W1) land while this unit finishes, and the
-// third boundary barrier is gone.
+// one per-lane address per tap column (three registers instead of eight) plus immediates.
+// The DMA form also has NO EPILOGUE TILE and no boundary barriers: its consumers multiply channels x pixels (A = weights, B =
+// patch; the weight rows a lane reads are permuted so that accumulator rows 4 lq + j of a pair of 16-channel blocks are 8
+// consecutive channels of one pixel) and store 16 bytes per pixel and block pair straight from the accumulators; BatchNorm
+// sums are reduced over the 16 pixel lanes with DPP adds and written as one partial row per (unit, consumer pixel half).
+// Producers and consumers then run through unit boundaries like through any other step: the next unit's first patch chunk
+// and weight steps land under this unit's last steps, and the 128 two-byte LDS stores + three barriers + 512-thread store
+// pass of the staged epilogue (8 k cycles per unit: 30 % of a Cin = 128 unit) become ~100 vector instructions of the
+// consumers alone.
 __device__ __attribute__((aligned(256))) unsigned char g_pipe_zero_page[256];
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
+template <int CTRL> __device__ __forceinline__ float pipe_dpp_add(float v) {
+  const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+  return v + __int_as_float(x);
+}
+// sum over the 16 lanes of a DPP row, result in every lane: xor 1, xor 2 (quad permutes), half mirror, mirror -- a fixed tree
+__device__ __forceinline__ float pipe_row16_sum(float v) {
+  v = pipe_dpp_add<0xB1>(v);
+  v = pipe_dpp_add<0x4E>(v);
+  v = pipe_dpp_add<0x141>(v);
+  v = pipe_dpp_add<0x140>(v);
+  return v;
+}
 
 template <int TWL, bool PRO, int BN, bool M16, bool DMA = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) {
@@ -549,11 +578,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   // ---- the part of the epilogue all 512 threads run: BN-statistics reduction over the consumer rows and
   // the 16-byte coalesced NHWC stores of the staged tile
   constexpr int OP = BN * E::ES + 16;
-  constexpr int OTOFF = DMA ? POFF + PB : POFF;    // DMA: P0 stays live across the unit boundary (next unit's first chunk)
-  constexpr int LDSEND = DMA ? (MAINB > OTOFF + BM * OP + WM * BN * 8 ? MAINB : OTOFF + BM * OP + WM * BN * 8) : MAINB;
+  constexpr int LDSEND = MAINB;                    // DMA: one trash KiB behind the ring (no epilogue tile)
   static_assert(DMA ? (LDSEND + 1024 <= 160 * 1024) : (BM * OP + WM * BN * 8 <= MAINB - POFF),
                 "epilogue tile fits behind the live ring slots");
-  char* const ot = smem + OTOFF;
+  char* const ot = smem + POFF;
   float* const red = (float*)(ot + BM * OP);
   auto store_tile = [&](auto FULLc) {
     constexpr bool FULL = decltype(FULLc)::value;
@@ -565,8 +593,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
         t1 += red[(w * BN + tid) * 2 + 0];
         t2 += red[(w * BN + tid) * 2 + 1];
       }
-      float2* dst = (float2*)a.stats + (size_t)umt * a.Ntot + un0 + tid;
+      // segk_conv_tiles() counts WM rows per unit for every layer of this kernel (the DMA form writes one per consumer pixel
+      // half): the staged form puts its sums into the first and zeros into the rest
+      float2* dst = (float2*)a.stats + ((size_t)umt * WM) * a.Ntot + un0 + tid;
       *dst = make_float2(t1, t2);
+#pragma unroll
+      for (int w = 1; w < WM; ++w) dst[(size_t)w * a.Ntot] = make_float2(0.f, 0.f);
     }
 #endif
     constexpr int CPR = BN * E::ES / 16;   // 16-byte chunks per pixel row of the tile
@@ -661,6 +693,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     issue_p(0, 0, I_0{}, I_N{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                   // B0
+    PIPE_STAMP(5);
     for (;;) {
       const int un = u + GW;
       const bool has_next = un < u_end;
@@ -674,37 +707,47 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
         issue_w(un0, s0 + 2, 2);
         if (!last) {
           issue_p(kc + 1, (kc + 1) & 1, I_0{}, I_H{});
+          PIPE_STAMP(0);
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL0) : "memory");     // the weights (older) have landed
         } else if (has_next) {
           patch_unit(nb, ny0, nx0);
           issue_p(0, 0, I_0{}, I_H{});
+          PIPE_STAMP(0);
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL0) : "memory");
         } else {
+          PIPE_STAMP(0);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        PIPE_STAMP(2);
         // raw s_barrier: __syncthreads() carries a fence that hipcc lowers to s_waitcnt vmcnt(0) -- it would drain the patch
         // pieces this step leaves in flight.  The DMA data a barrier publishes is covered by the counted wait above it.
         __builtin_amdgcn_s_barrier();
+        PIPE_STAMP(1);
         // ---- step TG1: weights of step s0 + 3 (slot 0: the next chunk's or the next unit's first step); rest of the patch
         if (!last) issue_w(un0, s0 + 3, 0);
         else if (has_next) issue_w(nn0, 0, 0);
         if (!last) issue_p(kc + 1, (kc + 1) & 1, I_H{}, I_N{});
         else if (has_next) issue_p(0, 0, I_H{}, I_N{});
+        PIPE_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PIPE_STAMP(2);
         __builtin_amdgcn_s_barrier();
+        PIPE_STAMP(1);
         // ---- step TG2: weights of step s0 + 4 (slot 1)
         if (!last) issue_w(un0, s0 + 4, 1);
         else if (has_next) issue_w(nn0, 1, 1);
+        PIPE_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PIPE_STAMP(2);
         __builtin_amdgcn_s_barrier();
+        PIPE_STAMP(1);
       }
-      __syncthreads();                                 // E1: the consumers have staged the output tile
-      if ((uy0 + TH <= H) && (ux0 + TW <= W)) store_tile(std::true_type{});
-      else store_tile(std::false_type{});
+      // no boundary: the consumers store their results from registers, and the ring slots the next unit's first steps write
+      // were released by the step barriers above
       if (!has_next) break;
-      __syncthreads();                                 // E2: tile consumed, [P1 | W2 | spare] may be rewritten
       u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
     }
+    PIPE_STAMP_OUT();
     return;
   }
   } else {
@@ -1037,8 +1080,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     else return smem + prow + laneA[mb] + t * PPIX;
   };
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-    laneB[nb] = ((wn * NB + nb) * 16 + lc) * WPIX + ((lq ^ ((0x1230 >> (4 * ((lc >> 2) & 3))) & 3)) << 4);
+  for (int nb = 0; nb < NB; ++nb) {
+    // DMA form: the lane's row of block nb is channel 8 (lc >> 2) + 4 (nb & 1) + (lc & 3) of the block pair's 32
+    const int row = DMA ? (wn * NB + (nb & ~1)) * 16 + 8 * (lc >> 2) + 4 * (nb & 1) + (lc & 3) : (wn * NB + nb) * 16 + lc;
+    laneB[nb] = row * WPIX + ((lq ^ ((0x1230 >> (4 * ((row >> 2) & 3))) & 3)) << 4);
+  }
 
   f32x4 acc[MB][NB];
   auto zero_acc = [&]() {
@@ -1066,6 +1112,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) Bf[nb] = *(const uint4*)(smem + wb + laneB[nb] + t * (BN * WPIX));
   };
+  // staged form: pixels x channels (A = patch); DMA form: channels x pixels (A = weights), see the epilogue
+  auto mma16 = [&](const uint4& pfrag, const uint4& wfrag, const f32x4& c) {
+    if constexpr (DMA) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, pfrag), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pfrag), __builtin_bit_cast(bf16x8, wfrag), c, 0, 0, 0);
+  };
   auto step = [&](auto TGc, int kc) {
     constexpr int TG = decltype(TGc)::value;
     const int prow = (kc & 1) * PB + TG * ROWP;
@@ -1088,9 +1139,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
-            acc[4 * hh + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i & 1][j]),
-                                                                          __builtin_bit_cast(bf16x8, fb[t][nb]), acc[4 * hh + j][nb],
-                                                                          0, 0, 0);
+            acc[4 * hh + j][nb] = mma16(fa[i & 1][j], fb[t][nb], acc[4 * hh + j][nb]);
             const int m = j * NB + nb;
             if ((m & 1) && !(PIPE_ABL & 4)) {
               const int r = m >> 1;   // 0 .. 7
@@ -1118,9 +1167,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-          acc[4 * hh + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i & 1][j]),
-                                                                        __builtin_bit_cast(bf16x8, fb[t][nb]), acc[4 * hh + j][nb],
-                                                                        0, 0, 0);
+          acc[4 * hh + j][nb] = mma16(fa[i & 1][j], fb[t][nb], acc[4 * hh + j][nb]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -1168,6 +1215,59 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     }
   };
 
+  // DMA form: the unit's results straight from the accumulators.  acc[mb][2k][j] / acc[mb][2k + 1][j] are channels
+  // 32 k + 8 lq + j / + 4 + j (of the wave's 64) of pixel 16 mb + lc (of the wave's 128): 8 consecutive channels = one 16-byte
+  // store per pixel block and block pair, 64 contiguous bytes per pixel from the four lq lanes.
+  auto direct_out = [&](auto FULLc) {
+    constexpr bool full = decltype(FULLc)::value;
+    const bool do_stats = (a.stats != nullptr);
+    const int m0 = wm * MB * 16 + lc;                        // the lane's pixel of block 0
+    const int ty0 = m0 >> TWL, tx0 = m0 & (TW - 1);
+    const size_t pix0 = ((size_t)(ub * H + uy0 + ty0)) * W + ux0 + tx0;
+#pragma unroll
+    for (int k = 0; k < NB / 2; ++k) {
+      const int nbase = un0 + wn * 64 + 32 * k;              // wave-uniform; a 32-channel group never straddles CO1
+      T* dch;
+      int pstride;
+      if (nbase < a.CO1) { dch = (T*)a.out + nbase + 8 * lq; pstride = a.CO1; }
+      else { dch = (T*)a.out2 + (nbase - a.CO1) + 8 * lq; pstride = a.CO2; }
+      T* const dpx = dch + pix0 * pstride;
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = a.bias ? a.bias[nbase + 8 * lq + e] : 0.f;
+      float s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int dty = (mb * 16) >> TWL, dtx = (mb * 16) & (TW - 1);     // compile-time per mb
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[mb][2 * k + (e >> 2)][e & 3] + bv[e];
+        bool in = true;
+        if (!full) {   // rare: pixels past the image edge are neither stored nor counted
+          in = (uy0 + ty0 + dty < H) && (ux0 + tx0 + dtx < W);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = in ? v[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+        const uint4 o = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+        if (in && !(PIPE_ABL & 8)) *(uint4*)(dpx + (size_t)(dty * W + dtx) * pstride) = o;
+        if (PIPE_ABL & 8) asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+      }
+      if (do_stats && !(PIPE_ABL & 16)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] = pipe_row16_sum(s1[e]); s2[e] = pipe_row16_sum(s2[e]); }
+        if (lc == 0) {
+          float2* const dst = (float2*)a.stats + ((size_t)umt * WM + wm) * a.Ntot + nbase + 8 * lq;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) *(float4*)(dst + e) = make_float4(s1[e], s2[e], s1[e + 1], s2[e + 1]);
+        }
+      }
+    }
+  };
+
   zero_acc();
   __syncthreads();                                     // B0
   PIPE_STAMP(5);
@@ -1178,21 +1278,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     const bool has_next = un < u_end;
     int nmt = 0, nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
     if (has_next) decode(un, nmt, nb, ny0, nx0, nn0);
+    // step barriers: a raw s_barrier.  __syncthreads() adds s_waitcnt lgkmcnt(0), which drains the fragment pre-reads of the next
+    // step that the last sub-step left in flight; every read of the slot this barrier releases has already been consumed by an
+    // MFMA (so it has returned), and the pre-reads target a slot that was published one barrier earlier.
     for (int kc = 0; kc < nchunks; ++kc) {
       step(std::integral_constant<int, 0>{}, kc);
       PIPE_STAMP(0);
-      __syncthreads();
+      step_barrier();
       PIPE_STAMP(1);
       step(std::integral_constant<int, 1>{}, kc);
       PIPE_STAMP(0);
-      __syncthreads();
+      step_barrier();
       PIPE_STAMP(1);
       step(std::integral_constant<int, 2>{}, kc);
       PIPE_STAMP(0);
-      __syncthreads();
+      step_barrier();
       PIPE_STAMP(1);
     }
     const bool full = (uy0 + TH <= H) && (ux0 + TW <= W);
+    if constexpr (DMA) {
+      if (PIPE_ABL & 32) { asm volatile("" ::"v"(acc[0][0][0])); }
+      else if (full) direct_out(std::true_type{});
+      else direct_out(std::false_type{});
+      PIPE_STAMP(2);
+      if (!has_next) break;
+      zero_acc();
+      u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
+      rdA(0, 0, 0, fa[0]);                             // (P0 / W0 of the next unit landed under this unit's last steps)
+      rdB(0, 0, fb[0]);
+      PIPE_STAMP(4);
+      continue;
+    }
     if (full) stage_tile(std::true_type{});
     else stage_tile(std::false_type{});
     PIPE_STAMP(2);
@@ -1204,7 +1320,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     zero_acc();
     __syncthreads();                                   // E2
     u = un; umt = nmt; ub = nb; uy0 = ny0; ux0 = nx0; un0 = nn0;
-    if constexpr (!DMA) __syncthreads();               // E3: the next unit's chunk 0 is in P0 (DMA: it landed before E1)
+    __syncthreads();                                   // E3: the next unit's chunk 0 is in P0
     PIPE_STAMP(4);
     rdA(0, 0, 0, fa[0]);
     rdB(0, 0, fb[0]);
@@ -1500,9 +1616,7 @@ int launch_pipe_m(ConvArgs a, hipStream_t st) {
   constexpr int PPIX = DMA ? 64 : (M16 ? 96 : PIXB), WPIX = M16 ? 64 : PIXB;
   constexpr int ROWP = DMA ? ((PW + 7) & ~7) * 64 : ((PW * PPIX + 255) & ~255);
   constexpr size_t ring = 3 * (size_t)(3 * BN * WPIX) + 2 * (size_t)PH * ROWP;
-  // DMA: the epilogue tile (+ statistics rows) starts behind [W0 | W1 | P0]; one trash KiB at the end
-  constexpr size_t epi = 2 * (size_t)(3 * BN * WPIX) + (size_t)PH * ROWP + (size_t)BM * (BN * 2 + 16) + (size_t)(4 / (BN / 64)) * BN * 8;
-  constexpr size_t lds = DMA ? (ring > epi ? ring : epi) + 1024 : ring + (NTHR / 2) * 16;   // + producers' trash slots
+  constexpr size_t lds = DMA ? ring + 1024 : ring + (NTHR / 2) * 16;   // + a trash KiB / the producers' trash slots
   static_assert(lds <= 160 * 1024, "conv3x3_pipe: LDS exceeds 160 KiB");
   a.twl = TWL;
   a.tiles_x = cdiv(a.W, TW);
@@ -1540,7 +1654,9 @@ int launch_pipe(ConvArgs a, hipStream_t st) {
     static const char* const nodma = getenv("SEGK_PIPE_DMA");  // "0": the register-staged producers of rounds 1-3 (A/B runs)
     const int nchunks = (a.CA + a.CB) / 32;
     const long long px = (long long)a.B * a.H * a.W;
-    const int cmax = a.CA > a.CB ? a.CA : a.CB;
+    int cmax = a.CA > a.CB ? a.CA : a.CB;
+    cmax = cmax > a.CO1 ? cmax : a.CO1;
+    cmax = cmax > a.CO2 ? cmax : a.CO2;
     if (m16 && !(nodma && nodma[0] == '0') && nchunks % 2 == 0 && px * cmax * 2 < 4294967296LL)
       return launch_pipe_m<TWL, PRO, BN, true, true>(a, st);
   }

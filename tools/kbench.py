@@ -77,6 +77,9 @@ def main():
                     # conv3x3_pipe_kernel (waves 0-3 consumers, 4-7 producers)
                     names = ["step work (MFMA | staging)", "step barrier wait", "stage tile | E1 wait", "store tile",
                              "E2..E3 (refill)", "prologue"]
+                    if not args.pro and os.environ.get("SEGK_PIPE_DMA", "1") != "0":     # LDS-DMA form (no prologue)
+                        names = ["step work (MFMA | DMA issue)", "step barrier wait", "direct epilogue | vmcnt wait", "-",
+                                 "zero + first reads", "prologue"]
                 print(f"      stamps over {t.shape[0]} workgroups: kernel {tot.mean():.0f} cycles per wave (min {tot.min():.0f} max {tot.max():.0f})")
                 for i, nm in enumerate(names):
                     sh = (t[:, :, i] / tot)

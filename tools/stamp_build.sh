@@ -5,7 +5,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/image_segmentation_amd/csrc
 mkdir -p $R/tools/ubench/bin/stamp_obj
-for f in api conv_igemm conv_rs convt_stream stem wgrad bn_pool pack head_loss resize vit gemm; do
+for f in api conv_igemm conv_rs convt_stream stem wgrad bn_pool pack head_loss resize vit gemm probe; do
   if [ "$f" = conv_rs ]; then X="-DSEGK_RS_STAMPS ${RS_ABL:+-DRS_ABL=$RS_ABL} ${RS_EXTRA}";
   elif [ "$f" = conv_igemm ]; then X="-DSEGK_PIPE_STAMPS ${PIPE_EXTRA}";
   elif [ "$f" = bn_pool ]; then X="${POOL_EXTRA}"; else X=""; fi
@@ -17,4 +17,5 @@ for f in api conv_igemm conv_rs convt_stream stem wgrad bn_pool pack head_loss r
 done
 OUT=$R/tools/ubench/bin/libsegk_stamp${RS_ABL:+_abl$RS_ABL}${RS_TAG}.so   # RS_TAG also names PIPE_EXTRA builds
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $R/tools/ubench/bin/stamp_obj/*.o
+python3 -c "import ctypes,sys; ctypes.CDLL(sys.argv[1])" $OUT   # every symbol resolves (a missing unit would only show on the GPU box)
 echo built $OUT
