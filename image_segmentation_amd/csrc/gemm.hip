@@ -16,6 +16,7 @@
 // over work units, contiguous unit ranges per XCD; consecutive units share their A rows through that XCD's L2.
 // The epilogue stages the fp32 accumulators through LDS (bias / activation applied) and stores 16-byte coalesced rows.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 #include "segk_internal.h"
 
@@ -237,10 +238,293 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmArgs g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same GEMM with LDS-DMA producers, 16x16x32 consumers and results straight from the accumulators -- the form
+// the 3x3 producer/consumer convolution took this round (conv_igemm.hip, DMA form), for the same reasons, plus two that are
+// specific to a plain GEMM:
+//   * it is STAGING-bound: a 256 x 128 tile needs 48 KiB per 64 K-elements = 1024 matrix cycles, i.e. 12 global loads and 12
+//     ds_write_b128 per producer wave and stage in the register-staged kernel above (the convolution re-uses a patch for nine
+//     taps and needs a third of that).  By LDS-DMA it is 12 instructions, none of which waits for data;
+//   * the consumers above start every stage by reading its first fragments (nothing is pre-read across the barrier: two stage
+//     slots) and read in groups.  Here the ring is five or six slots of one 32-element chunk each ((BM + 128) x 64 B, unpadded rows with
+//     the 16-byte piece XOR-ed by [0,3,2,1][(row >> 2) & 3]: conflict-free for plain and for permuted 16-row operand reads):
+//     chunk q + 2 has landed one barrier before it is needed, so the next chunk's fragments are read between this chunk's MFMAs;
+//   * BM = 320 (wave tile 160 x 64): M = 3152 rows (B = 16 x 197 tokens) are 10 row tiles instead of 13, so the CLIP MLP's fc1
+//     (N = 3072: 24 column tiles) is 240 units = ONE round on 256 CUs instead of 312 = two.
+// One barrier per chunk.  MFMA orientation: channels x rows (A = weights with the rows a lane reads
+// permuted so that accumulator rows 4 lq + j of a block pair are 8 consecutive output channels): 16-byte stores from
+// registers, bias / quick_gelu on the way, no epilogue tile, no boundary barriers -- the ring runs through unit boundaries.
+typedef __attribute__((address_space(3))) void* g_lds_vp;
+typedef const __attribute__((address_space(1))) void* g_glb_vp;
+typedef __attribute__((ext_vector_type(4))) float g_f32x4;
+
+template <int MODE, int BM>   // 0 plain, 1 pixel-shuffle store, 2 un-shuffle gather
+__global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GemmArgs g) {
+  constexpr int BN = 128;
+  constexpr int SLOT = (BM + BN) * 64;          // one chunk: A rows then weight rows
+  constexpr int MBW = BM / 32;                  // 16-row blocks per consumer wave (wave tile BM/2 x 64)
+  constexpr int G = MBW / 2;                    // blocks per sub-step
+  constexpr int NA = BM / 64;                   // A pieces (16 rows) per producer wave and chunk
+  constexpr int NPC = NA + 2;                   // pieces per producer wave and chunk (two weight pieces)
+  // Ring: one barrier per chunk.  During chunk q the consumers read slot q and pre-read the first fragments of chunk q + 1;
+  // chunks <= q + 2 have landed at the barrier that ends it, and the youngest SLACK = NSLOT - 3 chunks stay in flight across
+  // it (BM = 256: six slots, three chunks = ~1 us of matrix work in flight; BM = 320: five slots, two).  A first form with
+  // two-chunk stages left zero / one chunk in flight and ran at the DMA latency, not at the matrix rate (fc1 28.8 us).
+  constexpr int GD_NSLOT = (6 * SLOT <= 160 * 1024) ? 6 : 5;
+  constexpr int SLACK = GD_NSLOT - 3;
+  static_assert(BM % 64 == 0 && GD_NSLOT * SLOT <= 160 * 1024, "tile / ring geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long M = g.M;
+  const int N = g.N;
+  const int NT = N / BN;
+  const int MT = (int)((M + BM - 1) / BM);
+  const int KS = g.ksplit > 1 ? g.ksplit : 1;
+  const int U = MT * NT * KS;
+  const int xcd = blockIdx.x & 7, upx = (U + 7) >> 3;
+  const int GW = gridDim.x >> 3;
+  int u = xcd * upx + (blockIdx.x >> 3);
+  const int u_end = min(U, (xcd + 1) * upx);
+  if (u >= u_end) return;
+  const int nck = g.nchunks / KS;               // chunks per unit (even, >= 2)
+  const int HW = g.H * g.W;
+
+  if (wave >= 4) {
+    // ================================================ PRODUCERS ================================================
+    const int pw = wave - 4;
+    const int lrow = lane >> 2;
+    const unsigned lpc = (unsigned)(((lane & 3) ^ ((0x1230 >> (4 * ((lane >> 4) & 3))) & 3)) << 4);   // global piece of the lane's LDS slot
+    const unsigned wl_off = (unsigned)(lrow * 64) + lpc;
+    unsigned arow[NA];                           // byte offset of the lane's row of each A piece (unit of the fetch cursor)
+    int cu = u, cc = 0;                          // fetch cursor: unit, chunk within it
+    int cn0 = 0, ck0 = 0;                        // that unit's first weight row and first chunk
+    bool cok = true;
+    auto cursor_unit = [&]() {
+      const long m0 = (long)(cu / (NT * KS)) * BM;
+      cn0 = (cu % NT) * BN;
+      ck0 = ((cu / NT) % KS) * nck;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        long m = m0 + (pw + 4 * i) * 16 + lrow;
+        m = m < M ? m : M - 1;                   // rows past the end read a valid row; they are never stored
+        if (MODE == 2) {
+          const long b = m / HW;
+          const int r = (int)(m - b * HW), y = r / g.W, x = r - y * g.W;
+          arow[i] = (unsigned)(((((b * 2 * g.H + 2 * y) * 2 * g.W) + 2 * x) * (long)g.lda) * 2);
+        } else {
+          arow[i] = (unsigned)((m * (long)g.lda) * 2);
+        }
+      }
+    };
+    // the next chunk of the stream -> ring slot `slot`; false past the last unit
+    auto issue_chunk = [&](int slot) {
+      if (!cok) return false;
+      const int kc = ck0 + cc;
+      long koff;                                 // elements
+      if (MODE == 2) {
+        const int tap = kc / g.nchA, c2 = kc - tap * g.nchA;
+        koff = ((long)(tap >> 1) * 2 * g.W + (tap & 1)) * g.lda + c2 * 32;
+      } else {
+        koff = (long)kc * 32;
+      }
+      const char* const ab = (const char*)g.A + koff * 2 + lpc;
+      char* const sb = smem + slot * SLOT;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        __builtin_amdgcn_global_load_lds((g_glb_vp)(ab + arow[i]), (g_lds_vp)(sb + (pw + 4 * i) * 1024), 16, 0, 0);
+      const char* const wb = g.w + ((size_t)kc * N + cn0) * 64 + wl_off;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((g_glb_vp)(wb + (pw + 4 * i) * 1024), (g_lds_vp)(sb + BM * 64 + (pw + 4 * i) * 1024), 16, 0, 0);
+      if (++cc == nck) {
+        cc = 0;
+        cu += GW;
+        cok = cu < u_end;
+        if (cok) cursor_unit();
+      }
+      return true;
+    };
+    cursor_unit();
+    int q = 0;                                    // stream chunks issued so far
+    bool all = true;
+#pragma unroll
+    for (int i = 0; i < 2 + SLACK; ++i) { all = issue_chunk(q % GD_NSLOT) && all; ++q; }
+    if (all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLACK * NPC) : "memory");     // chunks 0 and 1 have landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // B0
+    for (;;) {
+      const int un = u + GW;
+      const bool has_next = un < u_end;
+      for (int c = 0; c < nck; ++c) {
+        // the next chunk of the stream into the slot the previous stage released; all but the youngest SLACK chunks have
+        // landed at the barrier
+        const bool a1 = issue_chunk(q % GD_NSLOT);
+        ++q;
+        if (a1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLACK * NPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if (!has_next) break;
+      u = un;
+    }
+    return;
+  }
+
+  // ================================================= CONSUMERS =================================================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lc = lane & 15, lq = lane >> 4;
+  // activation rows: block mb of the wave = rows (wm * MBW + mb) * 16 + lc of the tile: one per-lane address + immediates
+  const int laneX = (wm * MBW * 16 + lc) * 64 + ((lq ^ ((0x1230 >> (4 * ((lc >> 2) & 3))) & 3)) << 4);
+  int laneW[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int row = (wn * 4 + (nb & ~1)) * 16 + 8 * (lc >> 2) + 4 * (nb & 1) + (lc & 3);   // channel 8 (lc >> 2) + 4 (nb & 1) + (lc & 3) of the pair's 32
+    laneW[nb] = BM * 64 + row * 64 + ((lq ^ ((0x1230 >> (4 * ((row >> 2) & 3))) & 3)) << 4);
+  }
+  g_f32x4 acc[MBW][4];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  uint4 fx[2][G], fw[2][4];
+  auto rdX = [&](int sb, int grp, int j) { return *(const uint4*)(smem + sb + laneX + (grp * G + j) * 1024); };
+  auto rdW = [&](int sb, int nb) { return *(const uint4*)(smem + sb + laneW[nb]); };
+  // one chunk (K = 32): two sub-steps of G x 4 MFMAs; the fragments of the next sub-step / next chunk are read between them
+  // (one ds_read_b128 behind every second MFMA).  par = parity of the chunk in the stream (fw buffer)
+  auto chunk = [&](int sb, int sb_next, auto PARc) {
+    constexpr int par = decltype(PARc)::value;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          acc[grp * G + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[par][nb]),
+                                                                         __builtin_bit_cast(bf16x8, fx[grp][j]), acc[grp * G + j][nb], 0, 0, 0);
+          const int m = j * 4 + nb;
+          if (m & 1) {
+            const int r = m >> 1;
+            if (grp == 0) {
+              if (r < G) fx[1][r] = rdX(sb, 1, r);                       // this chunk's second half
+            } else {
+              if (r < 4) fw[par ^ 1][r] = rdW(sb_next, r);               // next chunk: weights first, then its first half
+              else if (r - 4 < G) fx[0][r - 4] = rdX(sb_next, 0, r - 4);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  };
+  // the unit's results straight from the accumulators: acc[mb][2k][j] / acc[mb][2k + 1][j] = channels 32 k + 8 lq + j / + 4 + j
+  // (of the wave's 64) of row 16 mb + lc (of the wave's BM / 2)
+  auto direct_out = [&](int uu) {
+    const long m0 = (long)(uu / (NT * KS)) * BM + wm * (BM / 2) + lc;
+    const int n0 = (uu % NT) * BN + wn * 64;
+    const int split = (uu / NT) % KS;
+    bf16_t* const obase = (bf16_t*)g.out + (size_t)split * g.split_stride;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int n8 = n0 + 32 * k + 8 * lq;
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = (g.bias && split == 0) ? g.bias[n8 + e] : 0.f;   // split-K: the bias rides on split 0
+      int tap = 0, co = n8;
+      if (MODE == 1) { tap = n8 / g.Cout; co = n8 - tap * g.Cout; }
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb) {
+        const long gm = m0 + mb * 16;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = acc[mb][2 * k + (e >> 2)][e & 3] + bv[e];
+          if (g.act) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));       // quick_gelu (CLIPMLP)
+        }
+        const uint4 o = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+        if (gm < M) {
+          bf16_t* dst;
+          if (MODE == 1) {   // pixel-shuffle store: channel n of the GEMM is (tap, co) of output pixel (2y + tap/2, 2x + tap%2)
+            const long b = gm / HW;
+            const int r = (int)(gm - b * HW), y = r / g.W, x = r - y * g.W;
+            dst = (bf16_t*)g.out + ((((b * 2 * g.H + 2 * y + (tap >> 1)) * 2 * g.W) + 2 * x + (tap & 1)) * (long)g.Cout + co);
+          } else {
+            dst = obase + gm * (long)N + n8;
+          }
+          *(uint4*)dst = o;
+        }
+      }
+    }
+  };
+
+  zero_acc();
+  __syncthreads();                                   // B0
+  int q = 0;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) fw[0][nb] = rdW(0, nb);
+#pragma unroll
+  for (int j = 0; j < G; ++j) fx[0][j] = rdX(0, 0, j);
+  for (;;) {
+    const int un = u + GW;
+    const bool has_next = un < u_end;
+    for (int c = 0; c < nck; c += 2) {
+      const int s0 = (q % GD_NSLOT) * SLOT, s1 = ((q + 1) % GD_NSLOT) * SLOT, s2 = ((q + 2) % GD_NSLOT) * SLOT;
+      chunk(s0, s1, std::integral_constant<int, 0>{});
+      __syncthreads();
+      chunk(s1, s2, std::integral_constant<int, 1>{});
+      q += 2;
+      __syncthreads();
+    }
+    direct_out(u);
+    if (!has_next) break;
+    zero_acc();
+    u = un;
+  }
+}
+
 static int g_num_cus() { return segk_num_cus(); }
+
+template <int MODE, int BM>
+int launch_dma(const GemmArgs& g, hipStream_t st) {
+  auto kern = gemm_dma_kernel<MODE, BM>;
+  static bool attr_set[SEGK_MAX_DEVICES] = {};     // per device: the attribute is device state
+  const int dev_ = segk_device_index();
+  if (!attr_set[dev_]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SEGK_FAIL(-3, "gemm_dma: cannot raise dynamic LDS limit");
+    attr_set[dev_] = true;
+  }
+  const long U = ((g.M + BM - 1) / BM) * (g.N / 128) * (g.ksplit > 1 ? g.ksplit : 1);
+  const int per_xcd = (int)((U + 7) / 8);
+  int gw = g_num_cus() / 8;
+  if (gw > per_xcd) gw = per_xcd;
+  constexpr int SLOT = (BM + 128) * 64, NSLOT = (6 * SLOT <= 160 * 1024) ? 6 : 5;
+  hipLaunchKernelGGL(kern, dim3(8 * gw), dim3(512), NSLOT * SLOT, st, g);
+  SEGK_CHECK_LAUNCH("gemm_dma");
+  return 0;
+}
+
+// rounds of `units` work units on the chip's CUs, in units of one 256-row tile's time
+static double gemm_rounds(long M, int N, int ks, int bm) {
+  const long units = ((M + bm - 1) / bm) * (long)(N / 128) * ks;
+  const long cus = g_num_cus();
+  return (double)((units + cus - 1) / cus) * bm / 256.0;
+}
 
 template <int MODE>
 int launch_mode(const GemmArgs& g, hipStream_t st) {
+  // LDS-DMA form (round 4) unless SEGK_GEMM_DMA=0 (A/B runs) or a source is too large for 32-bit byte offsets per DMA lane;
+  // 320-row tiles where they need fewer rounds on the chip than 256-row tiles (M = 3152: fc1 240 units instead of 312)
+  static const char* const nodma = getenv("SEGK_GEMM_DMA");
+  const long arows = MODE == 2 ? 4 * g.M : g.M;
+  if (!(nodma && nodma[0] == '0') && arows * (long)g.lda * 2 < 4294967296L && (g.nchunks / (g.ksplit > 1 ? g.ksplit : 1)) % 2 == 0) {
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    static const char* const bmf = getenv("SEGK_GEMM_BM");     // "256" / "320": force a tile height (A/B runs)
+    const bool use320 = bmf ? (bmf[0] == '3') : gemm_rounds(g.M, g.N, ks, 320) < gemm_rounds(g.M, g.N, ks, 256);
+    return use320 ? launch_dma<MODE, 320>(g, st) : launch_dma<MODE, 256>(g, st);
+  }
   auto kern = gemm_pipe_kernel<MODE>;
   static bool attr_set[SEGK_MAX_DEVICES] = {};     // per device: the attribute is device state
   const int dev_ = segk_device_index();
