@@ -4,7 +4,7 @@
 # Output under gpurun_out/final/ ; copy the summaries into profiles/ afterwards.
 #   tools/collect_profiles.sh [round tag, default r03]
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/final
 mkdir -p $OUT
