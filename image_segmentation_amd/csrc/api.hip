@@ -112,8 +112,7 @@ int segk_conv_tiles(int B, int H, int W, int Cin, int Cout, int dtype) {
   const int pk = segk_conv_use_pipe(Cin, Cout, dtype);
   const int bm = segk_conv_use_ws(Cin, Cout, dtype) ? 256 : pk ? 32768 / pk : segk_conv_bm(0, Cout);
   const int twl = segk_conv_twl(bm, W);
-  // producer/consumer kernel: one row per unit and consumer pixel half (its LDS-DMA form writes them from registers)
-  return B * cdiv(W, 1 << twl) * cdiv(H, bm >> twl) * (pk ? 4 / (pk / 64) : 1);
+  return B * cdiv(W, 1 << twl) * cdiv(H, bm >> twl);
 }
 
 int segk_conv3x3(const void* srcA, const void* srcB, const void* wpacked, const float* bias, const float* scale,

@@ -14,7 +14,7 @@
 #include "../../include/segk.h"
 
 namespace {
-__device__ unsigned long long g_tickets[TICKET_SLOTS * TICKET_GROUPS];     // any content is a valid start (ticket.hpp)
+__device__ unsigned g_tickets[TICKET_SLOTS * TICKET_GROUPS];     // zeroed per launch by the host (ticket.hpp)
 
 // block = CVB channel-vectors x ROWS pixel lanes (CVB*ROWS <= 256); grid.y covers channel blocks.
 struct Lanes {
@@ -185,11 +185,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
                                                                 float* rvar, float momentum, float eps,
                                                                 float* scale, float* shift, float* mean_out,
                                                                 float* rstd_out, double* __restrict__ scratch,
-                                                                unsigned long long* __restrict__ tickets, unsigned gen) {
+                                                                unsigned* __restrict__ tickets) {
   __shared__ double sh[8][32][2];
   __shared__ int last;
   stats_chunk(part, MT, C, scratch, sh);
-  if (!last_arriver(tickets + blockIdx.x, gen, gridDim.y, &last)) return;
+  if (!last_arriver(tickets + blockIdx.x, gridDim.y, &last)) return;
   finalize_channels(scratch, (int)gridDim.y, C, C_real, count, conv_bias, gamma, beta, rmean, rvar, momentum, eps, 1, scale,
                     shift, mean_out, rstd_out, sh);
 }
@@ -679,27 +679,26 @@ static inline void lane_geometry(int C, int vec, int* cvb, int* rows, int* gy) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-TicketRef segk_ticket_slot() {
+unsigned* segk_ticket_slot(int groups, hipStream_t st) {
   static std::atomic<unsigned> n{0};
-  static unsigned long long* base[SEGK_MAX_DEVICES] = {};      // per device: the symbol lives in that device's module image
+  static unsigned* base[SEGK_MAX_DEVICES] = {};      // per device: the symbol lives in that device's module image
   const int dev = segk_device_index();
-  if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_tickets)) != hipSuccess) return {nullptr, 0u};
-  const unsigned k = n.fetch_add(1, std::memory_order_relaxed);
-  // generation: the launch serial folded away from 0xffffffff (what segk_debug_poison_tickets writes) -- a slot comes round
-  // every TICKET_SLOTS launches, a generation every 2^32 - 1, so a stale word never carries the generation of the launch
-  // that finds it
-  return {base[dev] + (size_t)(k % TICKET_SLOTS) * TICKET_GROUPS, k % 0xffffffffu};
+  if (groups < 1 || groups > TICKET_GROUPS) return nullptr;
+  if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
+  unsigned* const p = base[dev] + (size_t)(n.fetch_add(1, std::memory_order_relaxed) % TICKET_SLOTS) * TICKET_GROUPS;
+  // zero what this launch will count in, in stream order right before it (graph-capture safe: a memset node)
+  if (hipMemsetAsync(p, 0, (size_t)groups * sizeof(unsigned), st) != hipSuccess) return nullptr;
+  return p;
 }
 
-// diagnostics / tests: overwrite every ticket word of the current device with `pattern` (what an aborted launch, or a stray
-// store, would leave behind); every launch that draws a ticket afterwards must still elect exactly one finisher
+// diagnostics / tests: overwrite every ticket counter of the current device with the low 32 bits of `pattern` (what an
+// aborted launch, or a stray store, would leave behind); every launch that draws a ticket afterwards must still elect
+// exactly one finisher
 int segk_debug_poison_tickets_impl(unsigned long long pattern, hipStream_t st) {
-  TicketRef t = segk_ticket_slot();
-  SEGK_REQUIRE(t.words != nullptr, "poison_tickets: no ticket array");
-  unsigned long long* base = nullptr;
+  unsigned* base = nullptr;
   SEGK_REQUIRE(hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_tickets)) == hipSuccess, "poison_tickets: no ticket array");
-  static unsigned long long host[TICKET_SLOTS * TICKET_GROUPS];
-  for (int i = 0; i < TICKET_SLOTS * TICKET_GROUPS; ++i) host[i] = pattern;
+  static unsigned host[TICKET_SLOTS * TICKET_GROUPS];
+  for (int i = 0; i < TICKET_SLOTS * TICKET_GROUPS; ++i) host[i] = (unsigned)pattern;
   SEGK_REQUIRE(hipMemcpyAsync(base, host, sizeof(host), hipMemcpyHostToDevice, st) == hipSuccess, "poison_tickets: copy failed");
   SEGK_REQUIRE(hipStreamSynchronize(st) == hipSuccess, "poison_tickets: sync failed");
   return 0;
@@ -722,10 +721,10 @@ int segk_bn_finalize_impl(const float* part, int MT, int C, int C_real, double c
   }
   if (training) {
     SEGK_REQUIRE(C / 32 <= TICKET_GROUPS, "bn_finalize: at most %d channels", 32 * TICKET_GROUPS);
-    const TicketRef tk = segk_ticket_slot();
-    SEGK_REQUIRE(tk.words != nullptr, "bn_finalize: no ticket array");
+    unsigned* const tickets = segk_ticket_slot(C / 32, st);
+    SEGK_REQUIRE(tickets != nullptr, "bn_finalize: no ticket array");
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 32, NCH), dim3(256), 0, st, part, MT, C, C_real, count, conv_bias,
-                       gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean, rstd, scratch, tk.words, tk.gen);
+                       gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean, rstd, scratch, tickets);
     SEGK_CHECK_LAUNCH("bn_stats_finalize");
     return 0;
   }

@@ -578,7 +578,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   // ---- the part of the epilogue all 512 threads run: BN-statistics reduction over the consumer rows and
   // the 16-byte coalesced NHWC stores of the staged tile
   constexpr int OP = BN * E::ES + 16;
-  constexpr int LDSEND = MAINB;                    // DMA: one trash KiB behind the ring (no epilogue tile)
+  constexpr int LDSEND = MAINB;                    // DMA: one trash KiB behind the ring (no epilogue tile), then the
+  constexpr int STOFF = LDSEND + 1024;             // statistics exchange: [WM][WN][64 ch][2] floats + one flag per consumer wave
   static_assert(DMA ? (LDSEND + 1024 <= 160 * 1024) : (BM * OP + WM * BN * 8 <= MAINB - POFF),
                 "epilogue tile fits behind the live ring slots");
   char* const ot = smem + POFF;
@@ -593,12 +594,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
         t1 += red[(w * BN + tid) * 2 + 0];
         t2 += red[(w * BN + tid) * 2 + 1];
       }
-      // segk_conv_tiles() counts WM rows per unit for every layer of this kernel (the DMA form writes one per consumer pixel
-      // half): the staged form puts its sums into the first and zeros into the rest
-      float2* dst = (float2*)a.stats + ((size_t)umt * WM) * a.Ntot + un0 + tid;
+      float2* dst = (float2*)a.stats + (size_t)umt * a.Ntot + un0 + tid;
       *dst = make_float2(t1, t2);
-#pragma unroll
-      for (int w = 1; w < WM; ++w) dst[(size_t)w * a.Ntot] = make_float2(0.f, 0.f);
     }
 #endif
     constexpr int CPR = BN * E::ES / 16;   // 16-byte chunks per pixel row of the tile
@@ -1215,6 +1212,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
     }
   };
 
+  int stat_seq = 0;                                          // DMA form: units this wave has written statistics for
+  if constexpr (DMA) {
+    if (lane == 0) ((volatile int*)(smem + STOFF + WM * WN * 64 * 8))[wave] = 0;   // flags (consumer waves = wm * WN + wn), before B0
+  }
   // DMA form: the unit's results straight from the accumulators.  acc[mb][2k][j] / acc[mb][2k + 1][j] are channels
   // 32 k + 8 lq + j / + 4 + j (of the wave's 64) of pixel 16 mb + lc (of the wave's 128): 8 consecutive channels = one 16-byte
   // store per pixel block and block pair, 64 contiguous bytes per pixel from the four lq lanes.
@@ -1259,11 +1260,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
       if (do_stats && !(PIPE_ABL & 16)) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] = pipe_row16_sum(s1[e]); s2[e] = pipe_row16_sum(s2[e]); }
-        if (lc == 0) {
-          float2* const dst = (float2*)a.stats + ((size_t)umt * WM + wm) * a.Ntot + nbase + 8 * lq;
+        if (lc == 0) {   // the wave's sums over its 128 pixels -> its slot of the exchange area
+          float4* const dst = (float4*)(smem + STOFF) + ((wm * WN + wn) * 64 + 32 * k + 8 * lq) / 2;
 #pragma unroll
-          for (int e = 0; e < 8; e += 2) *(float4*)(dst + e) = make_float4(s1[e], s2[e], s1[e + 1], s2[e + 1]);
+          for (int e = 0; e < 8; e += 2) dst[e / 2] = make_float4(s1[e], s2[e], s1[e + 1], s2[e + 1]);
         }
+      }
+    }
+    if (do_stats && !(PIPE_ABL & 16)) {
+      // ONE statistics row per unit: the consumer waves of a channel half (same wn, WM pixel parts) meet in LDS -- parts 1 ..
+      // WM - 1 publish (data, then a sequence flag), part 0 waits for their flags and adds the WM values per channel in part
+      // order (bit-stable) -- 512 contiguous bytes per wave instead of WM rows for segk_bn_finalize to walk (a first form with
+      // WM rows per unit made the BatchNorm finalize launches 0.17 -> 0.28 ms per step).  No wave waits on a wave that waits:
+      // the publishers never wait, and every wave passes at least one workgroup barrier between two units, so a slot is
+      // consumed long before it is rewritten.
+      volatile int* const flags = (volatile int*)(smem + STOFF + WM * WN * 64 * 8);
+      ++stat_seq;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slot is written
+      if (wm > 0) {
+        if (lane == 0) flags[wm * WN + wn] = stat_seq;
+      } else {
+#pragma unroll
+        for (int w = 1; w < WM; ++w)
+          while (flags[w * WN + wn] != stat_seq) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");                           // the slots are read after the flags, not before
+        const float2* const src = (const float2*)(smem + STOFF) + wn * 64 + lane;
+        float2 t = src[0];
+#pragma unroll
+        for (int w = 1; w < WM; ++w) {
+          const float2 q = src[w * WN * 64];
+          t.x += q.x;
+          t.y += q.y;
+        }
+        ((float2*)a.stats)[(size_t)umt * a.Ntot + un0 + wn * 64 + lane] = t;
       }
     }
   };
@@ -1616,7 +1645,8 @@ int launch_pipe_m(ConvArgs a, hipStream_t st) {
   constexpr int PPIX = DMA ? 64 : (M16 ? 96 : PIXB), WPIX = M16 ? 64 : PIXB;
   constexpr int ROWP = DMA ? ((PW + 7) & ~7) * 64 : ((PW * PPIX + 255) & ~255);
   constexpr size_t ring = 3 * (size_t)(3 * BN * WPIX) + 2 * (size_t)PH * ROWP;
-  constexpr size_t lds = DMA ? ring + 1024 : ring + (NTHR / 2) * 16;   // + a trash KiB / the producers' trash slots
+  // + a trash KiB and the statistics exchange (4 waves x 64 channels x 2 floats, 4 flags) / the producers' trash slots
+  constexpr size_t lds = DMA ? ring + 1024 + 4 * 64 * 8 + 64 : ring + (NTHR / 2) * 16;
   static_assert(lds <= 160 * 1024, "conv3x3_pipe: LDS exceeds 160 KiB");
   a.twl = TWL;
   a.tiles_x = cdiv(a.W, TW);

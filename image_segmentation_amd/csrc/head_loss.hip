@@ -424,7 +424,7 @@ __global__ __launch_bounds__(LT) void loss_fwd_kernel(const float* __restrict__ 
                                                        int ignore_index, float* __restrict__ part, int nll_log, float eps,
                                                        float smooth, float dice_weight, float ce_weight,
                                                        float* __restrict__ state, float* __restrict__ loss_out,
-                                                       unsigned long long* __restrict__ ticket, unsigned gen) {
+                                                       unsigned* __restrict__ ticket) {
   __shared__ float sh[LT / 64][LP];
   __shared__ int last;
   float a0 = 0.f, a1 = 0.f, aI[NC], aP[NC], aG[NC];
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(LT) void loss_fwd_kernel(const float* __restrict__ 
     part[(size_t)blockIdx.x * LP + i] = s2;
   }
   // the block that finishes last turns the partial rows into the loss (no second launch, nobody waits)
-  if (last_arriver(ticket, gen, gridDim.x, &last))
+  if (last_arriver(ticket, gridDim.x, &last))
     loss_finalize_block(part, (int)gridDim.x, C, cw, ignore_index, smooth, dice_weight, ce_weight, state, loss_out);
 }
 
@@ -782,13 +782,13 @@ int segk_loss_fwd_impl(const float* logits, const long long* labels, const float
   const long P = (long)N * HW;
   SEGK_REQUIRE(P < (1L << 31), "head / loss kernels index pixels with 32 bits: %ld pixels", P);
   const int nb = segk_loss_blocks(P);
-  const TicketRef tk = segk_ticket_slot();
-  SEGK_REQUIRE(tk.words != nullptr, "loss_fwd: no ticket array");
+  unsigned* const ticket = segk_ticket_slot(1, st);
+  SEGK_REQUIRE(ticket != nullptr, "loss_fwd: no ticket array");
   auto launch = [&](auto PROBc, auto NCc) {
     constexpr bool PR = decltype(PROBc)::value;
     constexpr int NC = decltype(NCc)::value;
     hipLaunchKernelGGL((loss_fwd_kernel<PR, NC>), dim3(nb), dim3(LT), 0, st, logits, labels, cw, P, HW, C, ignore_index, part,
-                       PR ? nll_log : 0, PR ? eps : 0.f, smooth, dice_weight, ce_weight, state, loss_out, tk.words, tk.gen);
+                       PR ? nll_log : 0, PR ? eps : 0.f, smooth, dice_weight, ce_weight, state, loss_out, ticket);
   };
   auto by_nc = [&](auto PROBc) {
     if (C <= 2) launch(PROBc, std::integral_constant<int, 2>{});

@@ -315,11 +315,11 @@ int segk_prob_loss_bwd(const float* probs, const int64_t* labels, const float* c
  * elapsed ticks of the constant 100 MHz counter (s_memrealtime): clock = out[2w] / out[2w+1] x 100 MHz.  bench.py puts
  * the median into its line so that box-to-box spread is explained by a number. */
 int segk_clock_probe(uint64_t* out, int blocks, int iters, int shape, segk_stream_t s);
-/* Overwrites every word of the device's ticket ring with `pattern` and waits for the copy.  The ring holds the arrival
- * counters of the kernels that finish a reduction in the launch that produced its partials (segk_bn_finalize above 1024
- * partial rows, segk_loss_fwd / segk_prob_loss_fwd); a word is {generation : 32 | arrivals : 32} and a launch starts its
- * count over when it finds another generation, so ANY content is a valid starting state.  Tests use this entry to leave
- * behind what an aborted launch or a stray store would (tests/test_gpu_kernels.py); generation 0xffffffff is never issued. */
+/* Overwrites every counter of the device's ticket ring with the low 32 bits of `pattern` and waits for the copy.  The ring
+ * holds the arrival counters of the kernels that finish a reduction in the launch that produced its partials
+ * (segk_bn_finalize above 1024 partial rows, segk_loss_fwd / segk_prob_loss_fwd); the host zeroes the counters a launch will
+ * use on that launch's stream right before it, so ANY content is a valid starting state.  Tests use this entry to leave
+ * behind what an aborted launch or a stray store would (tests/test_gpu_kernels.py). */
 int segk_debug_poison_tickets(uint64_t pattern, segk_stream_t s);
 
 /* ---- metric: argmax + confusion matrix (utils/MetricsHistory.py:65-75) ---------------------------

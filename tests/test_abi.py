@@ -78,13 +78,12 @@ def test_load_and_version(lib):
     assert so.segk_version() == lib.ABI_VERSION and so.segk_entry_count() == len(lib.SIGNATURES)
     assert so.segk_last_error() is not None
     # pure size queries work without a GPU
-    # producer/consumer kernel: one row per unit and consumer pixel part (its LDS-DMA form writes them from registers)
-    assert lib.query("segk_conv_tiles", 2, 32, 32, 256, 64, 1) == 2 * 2 * 1 * 4   # 16x32 tiles: bf16 64-ch output, long K; 4 parts
+    assert lib.query("segk_conv_tiles", 2, 32, 32, 256, 64, 1) == 2 * 2 * 1    # 16x32 tiles: bf16 64-ch output, long K
     assert lib.query("segk_conv_tiles", 2, 32, 32, 256, 64, 0) == 2 * 4 * 2    # 8x16 tiles: the same layer in fp32
     assert lib.query("segk_conv_tiles", 2, 32, 32, 64, 64, 1) == 8 * 1 * 4     # register-stationary kernel: one row of
     #                                                   partials per XCD slot (8), workgroup per slot (1) and wave slab (4)
     assert lib.query("segk_conv_tiles", 2, 32, 16, 64, 64, 1) == 2 * 1 * 2     # 16x16 tiles: weight-stationary kernel
-    assert lib.query("segk_conv_tiles", 2, 32, 32, 128, 128, 1) == 2 * 4 * 1 * 2   # 8x32 tiles for 128 channels; 2 parts
+    assert lib.query("segk_conv_tiles", 2, 32, 32, 128, 128, 1) == 2 * 4 * 1   # 8x32 tiles for 128 channels
     assert lib.query("segk_bn_stats_floats", 4, 64) == 4 * 64 * 2 + 32 * 64 * 4
     assert lib.query("segk_loss_state_floats") >= 4 + 3 * 8
 

@@ -50,10 +50,9 @@ chans = st.sampled_from([32, 64, 96, 128, 256, 512, 1024])
 def test_conv_tiles_properties(lib, B, H, W, cin, cout, dtype):
     t = lib.query("segk_conv_tiles", B, H, W, cin, cout, dtype)
     assert t >= 1
-    # never more rows than the smallest tile (8 x 16 pixels) would give -- the producer/consumer kernel writes one row per
-    # 128-pixel part of its 256- / 512-pixel tiles, whose partial tiles round up once more per axis -- or, register-stationary
-    # kernel, four rows per workgroup of at most 256
-    assert t <= max(B * ((H + 7) // 8 + 1) * ((W + 15) // 16 + 1), 1024)
+    # never more rows than the smallest tile (8 x 16 pixels) would give, or -- register-stationary kernel -- four rows
+    # per workgroup of at most 256
+    assert t <= max(B * ((H + 7) // 8) * ((W + 15) // 16), 1024)
     # the statistics buffer the host allocates from it holds every row (sum, sum of squares per channel) plus the
     # finalize scratch
     floats = lib.query("segk_bn_stats_floats", t, cout)
