@@ -270,6 +270,9 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, (sizeof(T) == 2 ?
   }
 }
 
+#ifdef SEGK_WGRAD_STAMPS
+__device__ unsigned long long g_wstamps[256 * 8 * 8];   // diagnostic build: [workgroup][wave][phase sums]
+#endif
 // ------------------------------------------------------------------------------------------------
 // bf16 3x3 weight gradient with LDS-DMA staging (global_load_lds: no staging VGPRs, no ds_write pass).
 //   U = the un-shifted operand  (8 x 16 pixel tile, WU blocks of 32 channels)
@@ -445,10 +448,22 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
     return __builtin_bit_cast(s16x8, make_uint4(o[0], o[1], o[2], o[3]));
   };
 
+  // Diagnostic build only (-DSEGK_WGRAD_STAMPS, tools/stamp_build.sh): per-wave cycle sums of a tile's phases -- [0] DMA issue +
+  // MFMA rows, [1] wait for the next tile's DMA, [2] barrier -- written over the head of the slab buffer; results are garbage.
+#ifdef SEGK_WGRAD_STAMPS
+  unsigned long long wst[3] = {0, 0, 0}, wlast, wt0;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wlast)::"memory");
+  wt0 = wlast;
+#define WSTAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+                       wst[i] += t_ - wlast; wlast = t_; } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#endif
   int t = s, cur = 0;
   if (t < ntiles) issue_tile(t, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  WSTAMP(2);
   // The two waves of a SIMD (w and w + NWV/2 of an eight-wave workgroup) issue the next tile's DMA at different points of
   // the tile: the first half in front of its MFMAs, the second half behind the MFMAs of dz row WGRAD_STAGGER_ROW -- one
   // wave's memory issue then runs beside its partner's matrix work instead of both queueing for the vector-memory pipe
@@ -538,8 +553,11 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
         }
       });
     }
+    WSTAMP(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile's DMA has landed
+    WSTAMP(1);
     __syncthreads();
+    WSTAMP(2);
     cur ^= 1;
   }
 
@@ -555,6 +573,16 @@ __global__ __launch_bounds__((WC * WI > 4 ? WC * WI : 4) * 64, 2) void wgrad_dma
         slab[((size_t)(n0 + wc * 32 + row) * NTAPS + tp) * K + k0 + wi * 32 + col] = acc[tp][r];
       }
   }
+#ifdef SEGK_WGRAD_STAMPS
+  {
+    unsigned long long t_;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   // the slab stores are out
+    if (lane == 0 && blockIdx.x < 256) {
+      unsigned long long* o = g_wstamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+      o[0] = wst[0]; o[1] = wst[1]; o[2] = wst[2]; o[3] = t_ - wlast; o[4] = t_ - wt0;
+    }
+  }
+#endif
 }
 
 template <int WC, int WI, bool PRO, bool RAG>
@@ -572,6 +600,9 @@ int launch_dma(const WgradArgs& a, hipStream_t st) {
     attr_set[dev_] = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3((WC * WI > 4 ? WC * WI : 4) * 64), lds, st, a);
+#ifdef SEGK_WGRAD_STAMPS
+  { void* sp = nullptr; if (hipGetSymbolAddress(&sp, HIP_SYMBOL(g_wstamps)) == hipSuccess) (void)hipMemcpyAsync(a.slabs, sp, sizeof(unsigned long long) * 256 * 8 * 8, hipMemcpyDeviceToDevice, st); }
+#endif
   SEGK_CHECK_LAUNCH("wgrad_dma");
   return 0;
 }
@@ -597,6 +628,9 @@ int launch_cfg(const WgradArgs& a, hipStream_t st) {
     attr_set[dev_] = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.S * NCT), dim3((WC * WI > 4 ? WC * WI : 4) * 64), lds, st, a);
+#ifdef SEGK_WGRAD_STAMPS
+  { void* sp = nullptr; if (hipGetSymbolAddress(&sp, HIP_SYMBOL(g_wstamps)) == hipSuccess) (void)hipMemcpyAsync(a.slabs, sp, sizeof(unsigned long long) * 256 * 8 * 8, hipMemcpyDeviceToDevice, st); }
+#endif
   SEGK_CHECK_LAUNCH("wgrad");
   return 0;
 }

@@ -90,6 +90,14 @@ def main():
                 ops.wgrad(g.data_ptr(), cout, x.data_ptr(), cin, 0, 0, B, hw, hw, 0, dt, "cuda", scale=sc, shift=sh)
             us = timeit(f, args.iters)
             print(f"wgrad {name:26s} {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {by/us/1e3:7.1f} GB/s(alg)")
+            if args.stamps:      # stamp build: wgrad_dma_kernel wrote per-wave phase cycle sums over the head of the slab buffer
+                slabs, _ = ops.wgrad(g.data_ptr(), cout, x.data_ptr(), cin, 0, 0, B, hw, hw, 0, dt, "cuda", scale=sc, shift=sh)
+                torch.cuda.synchronize()
+                t = slabs[:256 * 8 * 8 * 2].view(torch.int64).view(-1, 8).double().cpu()
+                t = t[(t[:, 4] > 0) & (t[:, 4] < 1e9)]
+                tot = t[:, 4]
+                for i, nm in enumerate(["DMA issue + MFMA rows", "wait for the next tile's DMA", "barrier", "slab stores"]):
+                    print(f"        {nm:30s} {100 * (t[:, i] / tot).mean():5.1f} %   ({t[:, i].mean():.0f} cycles of {tot.mean():.0f})")
 
 
 def convt():

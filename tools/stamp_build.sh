@@ -8,8 +8,9 @@ mkdir -p $R/tools/ubench/bin/stamp_obj
 for f in api conv_igemm conv_rs convt_stream stem wgrad bn_pool pack head_loss resize vit gemm probe; do
   if [ "$f" = conv_rs ]; then X="-DSEGK_RS_STAMPS ${RS_ABL:+-DRS_ABL=$RS_ABL} ${RS_EXTRA}";
   elif [ "$f" = conv_igemm ]; then X="-DSEGK_PIPE_STAMPS ${PIPE_EXTRA}";
+  elif [ "$f" = wgrad ]; then X="-DSEGK_WGRAD_STAMPS ${WGRAD_EXTRA}";
   elif [ "$f" = bn_pool ]; then X="${POOL_EXTRA}"; else X=""; fi
-  if [ "$f" = conv_rs ] || [ "$f" = conv_igemm ] || [ "$f" = bn_pool ] || [ ! -f $C/$f.o ]; then
+  if [ "$f" = conv_rs ] || [ "$f" = conv_igemm ] || [ "$f" = wgrad ] || [ "$f" = bn_pool ] || [ ! -f $C/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off $X -c $C/$f.hip -o $R/tools/ubench/bin/stamp_obj/$f.o
   else
     cp $C/$f.o $R/tools/ubench/bin/stamp_obj/$f.o
