@@ -127,6 +127,42 @@ def test_conv3x3_bf16_persistent_units(ops):
         assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("case", [(3, 128, 128, 37, 53), (2, 256, 192, 20, 24), (2, 128, 128, 13, 11), (1, 512, 256, 16, 16),
+                                  (5, 64 + 64, 64, 40, 72)], ids=["ragged_8x32", "bn64_16x32", "ragged_16x16", "one_tile", "two_sources_bn64"])
+def test_conv3x3_bf16_lds_dma_form(ops, case):
+    """The LDS-DMA form of the producer/consumer kernel (round 4: no prologue, an even number of 32-channel chunks): images that
+    are not whole tiles in either direction (zero-page halos AND partial tiles: pixels past the edge are neither stored nor
+    counted), both tile shapes, the 512-pixel x 64-channel variant, one unit per workgroup and many, two sources; with the
+    BatchNorm statistics row per unit (the consumer waves' LDS exchange) and, separately, a bias -- against fp32 torch on the
+    same bf16 inputs.  The canary pixels behind the output must stay untouched (results are stored from registers)."""
+    from image_segmentation_amd import _lib
+    dtype = torch.bfloat16
+    B, Cin, Cout, H, W = case
+    x = fill((B, Cin, H, W), 21, -1, 1)
+    w = fill((Cout, Cin, 3, 3), 22, -1, 1) / np.sqrt(9 * Cin)
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), padding=1)
+    if Cin == 128 and Cout == 64:
+        y, st = _conv_direct(ops, x[:, :64], w, dtype, xb=x[:, 64:], stats=True)
+    else:
+        y, st = _conv_direct(ops, x, w, dtype, stats=True)
+    assert (y - ref).abs().max().item() < tol(dtype, 1) * 1.5
+    s = st.sum(0)[:Cout]
+    assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2 * B * H * W * 0.05)
+    assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2)
+    # bias (no statistics) through the raw entry, with canary rows behind the output
+    if Cin != 128 or Cout != 64:
+        bias = fill((Cout,), 23, -1, 1)
+        xa = ops.to_act(dev(x), dtype); pa, CAp = ops.act_info(xa, dtype)
+        wp = ops.pack_conv(dev(w), Cin, 0, dtype, 0)
+        buf = torch.full((B * H * W + 64, Cout), 7.0, dtype=dtype, device="cuda")
+        _lib.call("segk_conv3x3", pa, 0, wp.data_ptr(), dev(bias).data_ptr(), 0, 0, buf.data_ptr(), 0, 0, B, H, W, CAp, 0,
+                  Cout, 0, 1, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = buf[:B * H * W].view(B, H, W, Cout).permute(0, 3, 1, 2).float().cpu()
+        assert (got - (ref + bias.view(1, -1, 1, 1))).abs().max().item() < tol(dtype, 1) * 1.5
+        assert bool((buf[B * H * W:].float() == 7.0).all())
+
+
 def test_conv3x3_bf16_register_stationary(ops):
     """conv_rs_kernel (Cin <= 64, 64-channel tiles, W > 16): many tiles per workgroup (the three-slot DMA ring wraps
     several times), partial tiles on both edges, one and two channel tiles, two destinations (the concat data gradient
