@@ -511,10 +511,38 @@ def cpu_baseline(S):
     torch.set_num_threads(best)
     sweep[best] += [step() for _ in range(3)]
     dt = sum(sweep[best]) / len(sweep[best])
+    # the FULL bench batch as well (SURVEY 8d asks for B = 32 beside the sub-sample): one warm-up + one timed step of the same
+    # oracle at B = 32 at the sub-sample's fastest thread count (~25 s on an EPYC 9575F; all 128 cores were measured 2 x slower:
+    # 26.2 vs 12.8 s per step)
+    full = {}
+    try:
+        Xf = fill((32, 3, S, S), 1, 0, 1); Yf = labels((32, S, S), 2, 3)
+        mf = unet_ref.unet(3, 3); fill_module(mf, 1000); mf.train()
+        optf = torch.optim.AdamW(mf.parameters(), weight_decay=0.01)
+
+        def step_full():
+            t0 = time.perf_counter()
+            optf.zero_grad()
+            losses_ref.cross_entropy(mf(Xf), Yf).backward()
+            optf.step()
+            return time.perf_counter() - t0
+        t_full = time.perf_counter()
+        for n in (best,):
+            torch.set_num_threads(n)
+            step_full()
+            full[str(n)] = round(step_full(), 3)
+            if time.perf_counter() - t_full > 45.0:      # bounded
+                break
+        del mf, optf, Xf, Yf
+    except Exception as e:                               # the baseline must never take the bench line down
+        full = {"error": repr(e)[:200]}
     torch.set_num_threads(prev_threads)
     out = {"value": round(Bc / dt, 3), "unit": "images/sec", "cores": best, "kind": "port",
            "cpu_model": cpu_model, "physical_cores_usable": phys, "logical_cpus_usable": usable,
            "thread_sweep_s_per_step": {str(n): round(v[0], 3) for n, v in sweep.items()},
+           "full_batch_B32_s_per_step": full,
+           "full_batch_B32_images_per_sec": (round(32.0 / min(v for v in full.values()), 3)
+                                             if full and all(isinstance(v, float) for v in full.values()) else None),
            "sample": f"oracle unet(3,3) fp32 train step (fwd+CE+bwd+AdamW), B={Bc} of 32 images 3x{S}x{S}; per thread "
                      f"setting 1 warm-up + 1 timed step, then {len(sweep[best])} timed steps in all at the fastest "
                      f"({best} threads on {cpu_model}, {phys} usable physical cores)"}
