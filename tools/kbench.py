@@ -44,14 +44,19 @@ def main():
     ap.add_argument("--pro", action="store_true")
     ap.add_argument("--no-stats", action="store_true", help="conv without the BatchNorm statistics epilogue")
     ap.add_argument("--lib", type=str, default="")
+    ap.add_argument("--list", type=str, default="", help="write the layers that ran (name|cin|cout|hw per line) to this file")
     ap.add_argument("--stamps", action="store_true", help="with the stamp build (tools/stamp_build.sh): print the conv_rs "
                     "kernel's per-phase cycle shares (read from the statistics buffer the diagnostic build overwrites)")
     args = ap.parse_args()
     dt = torch.bfloat16
     B = 32
+    ran = []
     for name, cin, cout, hw in LAYERS:
         if args.only and args.only not in name:
             continue
+        ran.append(f"{name}|{cin}|{cout}|{hw}")
+        if args.list:
+            open(args.list, "w").write("\n".join(ran) + "\n")
         x = torch.randn((B, hw, hw, cin), device="cuda").to(dt)
         g = torch.randn((B, hw, hw, cout), device="cuda").to(dt)
         w = torch.randn((cout, cin, 3, 3), device="cuda") / (3 * cin ** 0.5)

@@ -6,6 +6,7 @@ syntax errors until the GPU passes have already been paid for; tests/test_tools.
     pmc_post.py mfma_lds <out_dir> <repo_root>               MFMA busy / LDS conflict passes -> <out_dir>/pmc_mfma_lds.json
     pmc_post.py summary  <out_dir>                           mean counter value per kernel   -> <out_dir>/summary.txt
     pmc_post.py stats    <kernel_stats.csv> <steps>          per-step table of a rocprofv3 --stats summary
+    pmc_post.py layers   <out_dir> <launches_per_layer>      FETCH / WRITE passes of `kbench.py conv` -> <out_dir>/layers.txt
 """
 import collections
 import csv
@@ -134,9 +135,48 @@ def stats(path, steps):
               f"{float(r['AverageNs']) / 1e3:8.1f} us  {short(r['Name'])[:100]}")
 
 
+def layers(out, per_layer):
+    """Per-layer HBM traffic of `tools/kbench.py conv [--pro]` (tools/pmc_layers.sh): the conv dispatches arrive in LAYERS order,
+    `per_layer` launches each (3 warm-up + --iters); mean over a layer's launches, beside the layer's algorithmic bytes."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    conv = ("conv3x3_pipe", "conv_rs_kernel", "conv_ws_kernel", "conv_igemm_kernel", "stem_stream")
+    lines = []
+    for tag in ("plain", "pro"):
+        seq = {}
+        for ctr, d in (("FETCH_SIZE", f"{tag}_fetch"), ("WRITE_SIZE", f"{tag}_write")):
+            path = f"{out}/{d}/r_counter_collection.csv"
+            if not os.path.exists(path):
+                continue
+            rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == ctr and any(t in r["Kernel_Name"] for t in conv)]
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            seq[ctr] = [(short(r["Kernel_Name"]), float(r["Counter_Value"])) for r in rows]
+        if len(seq) < 2:
+            continue
+        layer_list = [ln.rstrip("\n").split("|") for ln in open(f"{out}/{tag}_layers.txt")]
+        n = min(len(seq["FETCH_SIZE"]), len(seq["WRITE_SIZE"])) // per_layer
+        lines.append(f"== kbench conv{' --pro' if tag == 'pro' else ''}: MB per launch, (2 x FETCH_SIZE + WRITE_SIZE) against "
+                     f"(Cin + Cout) x B x H x W x 2 B + weights")
+        lines.append(f"{'layer':28s} {'kernel':44s} {'alg in':>8s} {'alg out':>8s} {'fetch':>8s} {'write':>8s} {'ratio':>6s}")
+        for i in range(min(n, len(layer_list))):
+            name, cin, cout, hw = layer_list[i][0], int(layer_list[i][1]), int(layer_list[i][2]), int(layer_list[i][3])
+            fe = [v for _, v in seq["FETCH_SIZE"][i * per_layer:(i + 1) * per_layer]]
+            wr = [v for _, v in seq["WRITE_SIZE"][i * per_layer:(i + 1) * per_layer]]
+            kern = seq["FETCH_SIZE"][i * per_layer][0]
+            P = 32 * hw * hw
+            a_in = (P * cin * 2 + 9 * cin * cout * 2) / 1e6
+            a_out = P * cout * 2 / 1e6
+            f_mb = 2 * sum(fe) / len(fe) * 1024 / 1e6
+            w_mb = sum(wr) / len(wr) * 1024 / 1e6
+            lines.append(f"{name:28s} {kern[:44]:44s} {a_in:8.1f} {a_out:8.1f} {f_mb:8.1f} {w_mb:8.1f} {(f_mb + w_mb) / (a_in + a_out):6.2f}")
+    open(f"{out}/layers.txt", "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
-    if cmd == "traffic":
+    if cmd == "layers":
+        layers(sys.argv[2], int(sys.argv[3]))
+    elif cmd == "traffic":
         traffic(sys.argv[2], sys.argv[3])
     elif cmd == "mfma_lds":
         mfma_lds(sys.argv[2], sys.argv[3])
