@@ -1218,52 +1218,61 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const ConvArgs a) 
   }
   // DMA form: the unit's results straight from the accumulators.  acc[mb][2k][j] / acc[mb][2k + 1][j] are channels
   // 32 k + 8 lq + j / + 4 + j (of the wave's 64) of pixel 16 mb + lc (of the wave's 128): 8 consecutive channels = one 16-byte
-  // store per pixel block and block pair, 64 contiguous bytes per pixel from the four lq lanes.
+  // store per pixel block and channel group, 64 contiguous bytes per pixel from the four lq lanes.  Both groups of a pixel block
+  // are stored BACK TO BACK, so the two 64-byte halves of a pixel's 128-byte line reach L2 within one store pair: with the
+  // groups eight stores apart (the first form) the HBM write traffic of these launches was 20-36 % above the output size
+  // (half-written lines leaving L2 twice: 183 -> 138 MB at 128->128@128, profiles/r04_pmc_conv_layers.txt).  No bias here --
+  // every conv in front of a BatchNorm and every data gradient; a biased conv takes the staged form (launch_pipe): sixteen bias
+  // registers beside both groups' statistics spill.
   auto direct_out = [&](auto FULLc) {
     constexpr bool full = decltype(FULLc)::value;
+    static_assert(!DMA || NB == 4, "two 32-channel groups per consumer wave");
     const bool do_stats = (a.stats != nullptr);
     const int m0 = wm * MB * 16 + lc;                        // the lane's pixel of block 0
     const int ty0 = m0 >> TWL, tx0 = m0 & (TW - 1);
     const size_t pix0 = ((size_t)(ub * H + uy0 + ty0)) * W + ux0 + tx0;
+    T* dpx[2];
+    int pstr[2];
+    float s1[2][8], s2[2][8];
 #pragma unroll
-    for (int k = 0; k < NB / 2; ++k) {
+    for (int k = 0; k < 2; ++k) {
       const int nbase = un0 + wn * 64 + 32 * k;              // wave-uniform; a 32-channel group never straddles CO1
       T* dch;
-      int pstride;
-      if (nbase < a.CO1) { dch = (T*)a.out + nbase + 8 * lq; pstride = a.CO1; }
-      else { dch = (T*)a.out2 + (nbase - a.CO1) + 8 * lq; pstride = a.CO2; }
-      T* const dpx = dch + pix0 * pstride;
-      float bv[8];
+      if (nbase < a.CO1) { dch = (T*)a.out + nbase + 8 * lq; pstr[k] = a.CO1; }
+      else { dch = (T*)a.out2 + (nbase - a.CO1) + 8 * lq; pstr[k] = a.CO2; }
+      dpx[k] = dch + pix0 * pstr[k];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = a.bias ? a.bias[nbase + 8 * lq + e] : 0.f;
-      float s1[8], s2[8];
+      for (int e = 0; e < 8; ++e) { s1[k][e] = 0.f; s2[k][e] = 0.f; }
+    }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (int mb = 0; mb < MB; ++mb) {
+      const int dty = (mb * 16) >> TWL, dtx = (mb * 16) & (TW - 1);     // compile-time per mb
+      // rare (!full): pixels past the image edge are neither stored nor counted
+      const bool in = full || ((uy0 + ty0 + dty < H) && (ux0 + tx0 + dtx < W));
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int dty = (mb * 16) >> TWL, dtx = (mb * 16) & (TW - 1);     // compile-time per mb
+      for (int k = 0; k < 2; ++k) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[mb][2 * k + (e >> 2)][e & 3] + bv[e];
-        bool in = true;
-        if (!full) {   // rare: pixels past the image edge are neither stored nor counted
-          in = (uy0 + ty0 + dty < H) && (ux0 + tx0 + dtx < W);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = in ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+          v[e] = acc[mb][2 * k + (e >> 2)][e & 3];
+          if (!full) v[e] = in ? v[e] : 0.f;
+          s1[k][e] += v[e];
+          s2[k][e] = fmaf(v[e], v[e], s2[k][e]);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
         const uint4 o = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
-        if (in && !(PIPE_ABL & 8)) *(uint4*)(dpx + (size_t)(dty * W + dtx) * pstride) = o;
+        if (in && !(PIPE_ABL & 8)) *(uint4*)(dpx[k] + (size_t)(dty * W + dtx) * pstr[k]) = o;
         if (PIPE_ABL & 8) asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
       }
-      if (do_stats && !(PIPE_ABL & 16)) {
+    }
+    if (do_stats && !(PIPE_ABL & 16)) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[e] = pipe_row16_sum(s1[e]); s2[e] = pipe_row16_sum(s2[e]); }
+      for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[k][e] = pipe_row16_sum(s1[k][e]); s2[k][e] = pipe_row16_sum(s2[k][e]); }
         if (lc == 0) {   // the wave's sums over its 128 pixels -> its slot of the exchange area
           float4* const dst = (float4*)(smem + STOFF) + ((wm * WN + wn) * 64 + 32 * k + 8 * lq) / 2;
 #pragma unroll
-          for (int e = 0; e < 8; e += 2) dst[e / 2] = make_float4(s1[e], s2[e], s1[e + 1], s2[e + 1]);
+          for (int e = 0; e < 8; e += 2) dst[e / 2] = make_float4(s1[k][e], s2[k][e], s1[k][e + 1], s2[k][e + 1]);
         }
       }
     }
@@ -1679,15 +1688,16 @@ int launch_pipe(ConvArgs a, hipStream_t st) {
   static const char* const force = getenv("SEGK_PIPE_MFMA");  // A/B switch for tools/kbench.py / tools/ab_bench.sh: "16" or "32"
   const bool m16 = force ? (force[0] == '1') : true;
   if constexpr (!PRO) {
-    // LDS-DMA producers (round 4): layers without a BatchNorm prologue whose chunk count is even (the patch ring's parity
-    // across the unit boundary) and whose sources stay below 4 GiB (32-bit byte offsets per DMA lane)
+    // LDS-DMA producers (round 4): layers without a BatchNorm prologue and without a bias (the register epilogue carries none)
+    // whose chunk count is even (the patch ring's parity across the unit boundary) and whose sources stay below 4 GiB (32-bit
+    // byte offsets per DMA lane)
     static const char* const nodma = getenv("SEGK_PIPE_DMA");  // "0": the register-staged producers of rounds 1-3 (A/B runs)
     const int nchunks = (a.CA + a.CB) / 32;
     const long long px = (long long)a.B * a.H * a.W;
     int cmax = a.CA > a.CB ? a.CA : a.CB;
     cmax = cmax > a.CO1 ? cmax : a.CO1;
     cmax = cmax > a.CO2 ? cmax : a.CO2;
-    if (m16 && !(nodma && nodma[0] == '0') && nchunks % 2 == 0 && px * cmax * 2 < 4294967296LL)
+    if (m16 && !(nodma && nodma[0] == '0') && nchunks % 2 == 0 && px * cmax * 2 < 4294967296LL && a.bias == nullptr)
       return launch_pipe_m<TWL, PRO, BN, true, true>(a, st);
   }
   return m16 ? launch_pipe_m<TWL, PRO, BN, true>(a, st) : launch_pipe_m<TWL, PRO, BN, false>(a, st);

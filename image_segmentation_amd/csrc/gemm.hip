@@ -426,33 +426,40 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GemmArgs g) {
     const int n0 = (uu % NT) * BN + wn * 64;
     const int split = (uu / NT) % KS;
     bf16_t* const obase = (bf16_t*)g.out + (size_t)split * g.split_stride;
+    // both 32-channel groups of a row block back to back: the two 64-byte halves of a 128-byte output line reach L2 within one
+    // store pair (eight stores apart they left L2 half-written: +20-36 % HBM write bytes in the conv kernel's same epilogue)
+    float bv[2][8];
+    int tapk[2] = {0, 0}, cok[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int n8 = n0 + 32 * k + 8 * lq;
-      float bv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = (g.bias && split == 0) ? g.bias[n8 + e] : 0.f;   // split-K: the bias rides on split 0
-      int tap = 0, co = n8;
-      if (MODE == 1) { tap = n8 / g.Cout; co = n8 - tap * g.Cout; }
+      for (int e = 0; e < 8; ++e) bv[k][e] = (g.bias && split == 0) ? g.bias[n8 + e] : 0.f;   // split-K: the bias rides on split 0
+      cok[k] = n8;
+      if (MODE == 1) { tapk[k] = n8 / g.Cout; cok[k] = n8 - tapk[k] * g.Cout; }
+    }
 #pragma unroll
-      for (int mb = 0; mb < MBW; ++mb) {
-        const long gm = m0 + mb * 16;
+    for (int mb = 0; mb < MBW; ++mb) {
+      const long gm = m0 + mb * 16;
+      long pbase = 0;
+      if (MODE == 1) {   // pixel-shuffle store: channel n of the GEMM is (tap, co) of output pixel (2y + tap/2, 2x + tap%2)
+        const long b = gm / HW;
+        const int r = (int)(gm - b * HW), y = r / g.W, x = r - y * g.W;
+        pbase = ((b * 2 * g.H + 2 * y) * 2 * g.W) + 2 * x;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          v[e] = acc[mb][2 * k + (e >> 2)][e & 3] + bv[e];
+          v[e] = acc[mb][2 * k + (e >> 2)][e & 3] + bv[k][e];
           if (g.act) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));       // quick_gelu (CLIPMLP)
         }
         const uint4 o = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
         if (gm < M) {
           bf16_t* dst;
-          if (MODE == 1) {   // pixel-shuffle store: channel n of the GEMM is (tap, co) of output pixel (2y + tap/2, 2x + tap%2)
-            const long b = gm / HW;
-            const int r = (int)(gm - b * HW), y = r / g.W, x = r - y * g.W;
-            dst = (bf16_t*)g.out + ((((b * 2 * g.H + 2 * y + (tap >> 1)) * 2 * g.W) + 2 * x + (tap & 1)) * (long)g.Cout + co);
-          } else {
-            dst = obase + gm * (long)N + n8;
-          }
+          if (MODE == 1) dst = (bf16_t*)g.out + ((pbase + (long)(tapk[k] >> 1) * 2 * g.W + (tapk[k] & 1)) * (long)g.Cout + cok[k]);
+          else dst = obase + gm * (long)N + cok[k];
           *(uint4*)dst = o;
         }
       }

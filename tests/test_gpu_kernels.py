@@ -149,18 +149,21 @@ def test_conv3x3_bf16_lds_dma_form(ops, case):
     s = st.sum(0)[:Cout]
     assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2 * B * H * W * 0.05)
     assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=2e-2, atol=2e-2)
-    # bias (no statistics) through the raw entry, with canary rows behind the output
+    # through the raw entry with canary rows behind the output, no statistics: without a bias (the LDS-DMA form, results stored
+    # from registers) and with one (a biased conv takes the staged form: the register epilogue carries no bias)
     if Cin != 128 or Cout != 64:
         bias = fill((Cout,), 23, -1, 1)
         xa = ops.to_act(dev(x), dtype); pa, CAp = ops.act_info(xa, dtype)
         wp = ops.pack_conv(dev(w), Cin, 0, dtype, 0)
-        buf = torch.full((B * H * W + 64, Cout), 7.0, dtype=dtype, device="cuda")
-        _lib.call("segk_conv3x3", pa, 0, wp.data_ptr(), dev(bias).data_ptr(), 0, 0, buf.data_ptr(), 0, 0, B, H, W, CAp, 0,
-                  Cout, 0, 1, torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        got = buf[:B * H * W].view(B, H, W, Cout).permute(0, 3, 1, 2).float().cpu()
-        assert (got - (ref + bias.view(1, -1, 1, 1))).abs().max().item() < tol(dtype, 1) * 1.5
-        assert bool((buf[B * H * W:].float() == 7.0).all())
+        for bt in (None, dev(bias)):
+            buf = torch.full((B * H * W + 64, Cout), 7.0, dtype=dtype, device="cuda")
+            _lib.call("segk_conv3x3", pa, 0, wp.data_ptr(), bt.data_ptr() if bt is not None else 0, 0, 0, buf.data_ptr(), 0, 0,
+                      B, H, W, CAp, 0, Cout, 0, 1, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = buf[:B * H * W].view(B, H, W, Cout).permute(0, 3, 1, 2).float().cpu()
+            want = ref + bias.view(1, -1, 1, 1) if bt is not None else ref
+            assert (got - want).abs().max().item() < tol(dtype, 1) * 1.5
+            assert bool((buf[B * H * W:].float() == 7.0).all())
 
 
 def test_conv3x3_bf16_register_stationary(ops):
