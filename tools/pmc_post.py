@@ -140,8 +140,11 @@ def layers(out, per_layer):
     `per_layer` launches each (3 warm-up + --iters); mean over a layer's launches, beside the layer's algorithmic bytes."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     conv = ("conv3x3_pipe", "conv_rs_kernel", "conv_ws_kernel", "conv_igemm_kernel", "stem_stream")
+    wg = ("wgrad_dma_kernel", "wgrad_kernel", "stem_wgrad_kernel")
     lines = []
-    for tag in ("plain", "pro"):
+    for tag in ("plain", "pro", "wgrad"):
+        if tag == "wgrad":
+            conv = wg
         seq = {}
         for ctr, d in (("FETCH_SIZE", f"{tag}_fetch"), ("WRITE_SIZE", f"{tag}_write")):
             path = f"{out}/{d}/r_counter_collection.csv"
@@ -154,8 +157,9 @@ def layers(out, per_layer):
             continue
         layer_list = [ln.rstrip("\n").split("|") for ln in open(f"{out}/{tag}_layers.txt")]
         n = min(len(seq["FETCH_SIZE"]), len(seq["WRITE_SIZE"])) // per_layer
-        lines.append(f"== kbench conv{' --pro' if tag == 'pro' else ''}: MB per launch, (2 x FETCH_SIZE + WRITE_SIZE) against "
-                     f"(Cin + Cout) x B x H x W x 2 B + weights")
+        what = "wgrad" if tag == "wgrad" else "conv" + (" --pro" if tag == "pro" else "")
+        lines.append(f"== kbench {what}: MB per launch, (2 x FETCH_SIZE + WRITE_SIZE) against (Cin + Cout) x B x H x W x 2 B + "
+                     + ("the fp32 split-K slabs actually written (alg out: ONE fp32 weight-gradient tensor)" if tag == "wgrad" else "weights"))
         lines.append(f"{'layer':28s} {'kernel':44s} {'alg in':>8s} {'alg out':>8s} {'fetch':>8s} {'write':>8s} {'ratio':>6s}")
         for i in range(min(n, len(layer_list))):
             name, cin, cout, hw = layer_list[i][0], int(layer_list[i][1]), int(layer_list[i][2]), int(layer_list[i][3])
@@ -165,6 +169,9 @@ def layers(out, per_layer):
             P = 32 * hw * hw
             a_in = (P * cin * 2 + 9 * cin * cout * 2) / 1e6
             a_out = P * cout * 2 / 1e6
+            if tag == "wgrad":
+                a_in = P * (cin + cout) * 2 / 1e6
+                a_out = 9 * cin * cout * 4 / 1e6
             f_mb = 2 * sum(fe) / len(fe) * 1024 / 1e6
             w_mb = sum(wr) / len(wr) * 1024 / 1e6
             lines.append(f"{name:28s} {kern[:44]:44s} {a_in:8.1f} {a_out:8.1f} {f_mb:8.1f} {w_mb:8.1f} {(f_mb + w_mb) / (a_in + a_out):6.2f}")
